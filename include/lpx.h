@@ -1,0 +1,132 @@
+/*
+ * lpx.h -- C ABI of liblpx.so, the MI355X (gfx950) simplex / branch-and-bound engine.
+ *
+ * This is the drop-in boundary for the hot path of Jellyman750/Linear_Programming_Solver_LPR381.
+ * The reference is managed C# with no native interface of its own; each entry point below names
+ * the reference loop it replaces (paths relative to Linear_Programming_Solver/ in the reference)
+ * and is what a P/Invoke shim inside the reference's ILPAlgorithm implementations
+ * (Models/IPLAlgorithm.cs:5-8) would bind -- see INTEGRATION.md for that shim.
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned unless a *_free function is named;
+ *   - tableaux are row-major `double[R*C]` exactly as C#'s `double[R,C]` (zero-copy under
+ *     `fixed (double* p = T)`): R = m+1 rows with the objective row LAST, C = n+m+1 columns
+ *     with the RHS column LAST (Models/PrimalSimplex.cs:179-203);
+ *   - return value >= 0 is a solver status, < 0 an error; lpx_last_error() has the message;
+ *   - nothing here falls back to the CPU: without a gfx950 device every compute entry point
+ *     returns LPX_EDEVICE.
+ */
+#ifndef LPX_H
+#define LPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPX_ABI_VERSION 1
+
+/* ---- status (soft outcomes the reference reports as text) and errors (its exceptions) ------- */
+enum {
+    LPX_OPTIMAL    = 0,   /* "OPTIMAL"    Models/PrimalSimplex.cs:126 */
+    LPX_UNBOUNDED  = 1,   /* "UNBOUNDED"  Models/PrimalSimplex.cs:102-106 */
+    LPX_INFEASIBLE = 2,   /* "INFEASIBLE" Models/DualSimplex.cs:92-96 */
+    LPX_ITER_LIMIT = 3,   /* exception "Iteration limit exceeded." Models/PrimalSimplex.cs:95-96 */
+    LPX_RUNNING    = 4,   /* internal: loop not finished */
+    LPX_EINVAL     = -1,
+    LPX_EDEVICE    = -2,  /* no usable gfx950 device / HIP failure */
+    LPX_ENOMEM     = -3,
+    LPX_E_GE_PRESENT      = -10, /* Models/PrimalSimplex.cs:70 */
+    LPX_E_NEG_RHS         = -11, /* Models/PrimalSimplex.cs:75 */
+    LPX_E_REVISED_PRECOND = -12, /* Models/RevisedPrimalSimplex.cs:21 */
+    LPX_E_SINGULAR        = -13, /* Models/RevisedPrimalSimplex.cs:426 */
+    LPX_E_KNAP_SHAPE      = -14, /* Models/BranchAndBoundKnapsack.cs:66-69 */
+    LPX_E_UNKNOWN_ALGO    = -15, /* Models/LPSolver.cs:39-42 */
+    LPX_E_PARSE           = -16  /* Models/LPParser.cs exceptions */
+};
+
+/* Per-pivot event, fired on the calling thread between batches, in pivot order.  Replaces the
+ * reference's per-iteration `updatePivot(text, bool[,])` callback (Models/PrimalSimplex.cs:113-121),
+ * which formats the whole tableau; hosts that want to render it call lpx_tableau_download. */
+typedef void (*lpx_pivot_cb)(void* user, int iter, int row, int col);
+
+typedef struct lpx_stats {
+    int64_t pivots;          /* completed pivots */
+    int64_t launches;        /* kernel launches enqueued (including early-exit ones) */
+    double  loop_ms;         /* host wall time of the device-resident loop (no H2D/D2H) */
+    double  h2d_ms;          /* upload time of one-shot entry points */
+    double  d2h_ms;
+    double  update_ms_sum;   /* profile mode only: sum of HIP-event durations of the rank-1 update kernel */
+    int64_t update_launches; /* profile mode only: launches included in update_ms_sum */
+    int64_t fdf_pivots;      /* dual: pivots spent in ForceDualFeasibility */
+    int64_t cleanup_pivots;  /* dual, repaired mode: pivots of the primal clean-up phase */
+} lpx_stats;
+
+typedef struct lpx_run_opts {
+    double eps;        /* Eps, 1e-9 (Models/PrimalSimplex.cs:55, Models/DualSimplex.cs:13) */
+    double ratio_tol;  /* hysteresis of the ratio scans: 1e-9 primal (:235), 1e-12 dual (:85,:220) */
+    int    max_iter;   /* 10000 (Models/PrimalSimplex.cs:54, Models/DualSimplex.cs:39) */
+    int    fdf_guard;  /* dual: ForceDualFeasibility guard, 100 (Models/DualSimplex.cs:202) */
+    int    cleanup;    /* dual: 1 = repaired-mode primal clean-up phase */
+    int    batch;      /* pivots enqueued between host polls of the device state; 0 = default */
+    int    use_graph;  /* 1 = replay a captured hipGraph per batch, 0 = eager launches */
+    int    profile;    /* 1 = eager, every update kernel bracketed by HIP events (roofline leg) */
+} lpx_run_opts;
+
+void lpx_default_opts(lpx_run_opts* o, int dual);
+
+/* ---- library / device ----------------------------------------------------------------------- */
+int         lpx_abi_version(void);
+int         lpx_device_count(void);              /* 0 when no GPU is visible */
+int         lpx_init(int device);                /* binds this process to one GPU (one process per GPU) */
+int         lpx_last_error(char* buf, int len);  /* copies the last error message of this thread */
+int         lpx_device_name(char* buf, int len);
+
+/* ---- device-resident tableau ---------------------------------------------------------------- */
+/* HBM layout: row-major with the leading dimension padded to a multiple of 16 doubles (128 B) so
+ * that every row starts on a cache line and 16-byte vector accesses are aligned even for odd C. */
+typedef struct lpx_tableau lpx_tableau;
+
+int  lpx_tableau_create(int R, int C, lpx_tableau** out);
+void lpx_tableau_destroy(lpx_tableau* t);
+int  lpx_tableau_upload(lpx_tableau* t, const double* T, const int32_t* basis /* [R-1] or NULL */);
+int  lpx_tableau_download(lpx_tableau* t, double* T, int32_t* basis /* may be NULL */);
+int  lpx_tableau_snapshot(lpx_tableau* t);       /* keep a device copy of the current tableau+basis */
+int  lpx_tableau_restore(lpx_tableau* t);        /* D2D restore from the snapshot, resets the loop state */
+int  lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld);
+int  lpx_tableau_trace(lpx_tableau* t, int32_t* trace /* [2*cap] */, int cap, int* n);
+int  lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld);
+
+/* The hot loops.  Each iteration is two launches on one stream:
+ *   select  -- ChooseEntering + ChooseLeaving (+ pivot-row normalisation and pivot-column snapshot)
+ *   update  -- the rank-1 Gauss-Jordan update T[i,:] -= T[i,q] * T[r,:]  (i != r)            */
+
+/* PrimalSimplex.Solve's while(true), Models/PrimalSimplex.cs:92-124
+ * (ChooseEntering :205-220, ChooseLeaving :222-243, Pivot :245-257). */
+int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st);
+
+/* DualSimplex.Solve steps 3 and 5, Models/DualSimplex.cs:24 + :36-113
+ * (ForceDualFeasibility :195-228, leaving row :45-55, entering column :76-91, Pivot :232-246). */
+int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st);
+
+/* Pivot (Models/PrimalSimplex.cs:245-257) on caller-chosen positions: for k in [0,count):
+ * r = rows[k]; q = first column >= cols[k] (wrapping) with |T[r,q]| >= thresh; pivot(r,q).
+ * chosen[k] = q or -1.  The headline rank-1-update benchmark and the bitwise kernel parity tests. */
+int lpx_forced_pivots_run(lpx_tableau* t, const int32_t* rows, const int32_t* cols, int count,
+                          double thresh, int32_t* chosen, const lpx_run_opts* o, lpx_stats* st);
+
+/* ---- one-shot entry points on host buffers (what the C# shim binds) -------------------------- */
+/* Replaces the loop of PrimalSimplex.Solve (Models/PrimalSimplex.cs:92-124) on the `double[,]`
+ * built by BuildTableau (:179-203).  T and basis are updated in place. */
+int lpx_primal_tableau(double* T, int R, int C, int32_t* basis, double eps, int max_iter,
+                       lpx_pivot_cb cb, void* user, lpx_stats* st);
+/* Replaces ForceDualFeasibility + the loop of DualSimplex.Solve (Models/DualSimplex.cs:24,:36-113). */
+int lpx_dual_tableau(double* T, int R, int C, int32_t* basis, double eps, double ratio_tol,
+                     int fdf_guard, int max_iter, int cleanup,
+                     lpx_pivot_cb cb, void* user, lpx_stats* st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPX_H */

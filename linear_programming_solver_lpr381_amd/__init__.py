@@ -1,0 +1,10 @@
+"""lpx -- MI355X (gfx950) simplex / branch-and-bound engine behind the solver entry points of
+Jellyman750/Linear_Programming_Solver_LPR381 (Models/PrimalSimplex.cs, RevisedPrimalSimplex.cs,
+Branch&Bound.cs, BranchAndBoundKnapsack.cs).  The compute path is liblpx.so (hand-written HIP
+behind the C ABI of include/lpx.h); this package is the host-side binding and has no CPU fallback.
+"""
+from . import _lib
+from ._lib import LpxError, default_opts
+from .tableau import DeviceTableau, primal_tableau, dual_tableau
+
+__all__ = ["_lib", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau"]

@@ -1,0 +1,115 @@
+"""ctypes loader for liblpx.so -- the C ABI declared in include/lpx.h.
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no
+gfx950 device is visible when a compute entry point is called, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblpx.so")
+
+# status / error codes (include/lpx.h)
+OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, RUNNING = 0, 1, 2, 3, 4
+EINVAL, EDEVICE, ENOMEM = -1, -2, -3
+E_GE_PRESENT, E_NEG_RHS, E_REVISED_PRECOND, E_SINGULAR, E_KNAP_SHAPE, E_UNKNOWN_ALGO, E_PARSE = (
+    -10, -11, -12, -13, -14, -15, -16)
+
+STATUS_NAMES = {OPTIMAL: "OPTIMAL", UNBOUNDED: "UNBOUNDED", INFEASIBLE: "INFEASIBLE",
+                ITER_LIMIT: "ITER_LIMIT"}
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+PIVOT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)
+
+
+class Stats(C.Structure):
+    _fields_ = [("pivots", C.c_int64), ("launches", C.c_int64), ("loop_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("update_ms_sum", C.c_double),
+                ("update_launches", C.c_int64), ("fdf_pivots", C.c_int64), ("cleanup_pivots", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RunOpts(C.Structure):
+    _fields_ = [("eps", C.c_double), ("ratio_tol", C.c_double), ("max_iter", C.c_int),
+                ("fdf_guard", C.c_int), ("cleanup", C.c_int), ("batch", C.c_int),
+                ("use_graph", C.c_int), ("profile", C.c_int)]
+
+
+class LpxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"liblpx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads liblpx.so (built in-tree by __graft_entry__.build()). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lpx_abi_version.restype = C.c_int
+    L.lpx_device_count.restype = C.c_int
+    L.lpx_init.argtypes = [C.c_int]
+    L.lpx_last_error.argtypes = [C.c_char_p, C.c_int]
+    L.lpx_device_name.argtypes = [C.c_char_p, C.c_int]
+    L.lpx_default_opts.argtypes = [C.POINTER(RunOpts), C.c_int]
+    L.lpx_default_opts.restype = None
+    L.lpx_tableau_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.lpx_tableau_destroy.argtypes = [vp]
+    L.lpx_tableau_destroy.restype = None
+    L.lpx_tableau_upload.argtypes = [vp, dp, ip]
+    L.lpx_tableau_download.argtypes = [vp, dp, ip]
+    L.lpx_tableau_snapshot.argtypes = [vp]
+    L.lpx_tableau_restore.argtypes = [vp]
+    L.lpx_tableau_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.lpx_tableau_trace.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
+    L.lpx_tableau_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lpx_primal_run.argtypes = [vp, C.POINTER(RunOpts), PIVOT_CB, vp, C.POINTER(Stats)]
+    L.lpx_dual_run.argtypes = [vp, C.POINTER(RunOpts), PIVOT_CB, vp, C.POINTER(Stats)]
+    L.lpx_forced_pivots_run.argtypes = [vp, ip, ip, C.c_int, C.c_double, ip, C.POINTER(RunOpts),
+                                        C.POINTER(Stats)]
+    L.lpx_primal_tableau.argtypes = [dp, C.c_int, C.c_int, ip, C.c_double, C.c_int, PIVOT_CB, vp,
+                                     C.POINTER(Stats)]
+    L.lpx_dual_tableau.argtypes = [dp, C.c_int, C.c_int, ip, C.c_double, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, PIVOT_CB, vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib().lpx_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int) -> int:
+    """Raises LpxError for negative return codes, passes statuses through."""
+    if rc < 0:
+        raise LpxError(rc, last_error())
+    return rc
+
+
+def default_opts(dual: bool = False, **kw) -> RunOpts:
+    o = RunOpts()
+    lib().lpx_default_opts(C.byref(o), 1 if dual else 0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown run option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+NULL_CB = C.cast(None, PIVOT_CB)

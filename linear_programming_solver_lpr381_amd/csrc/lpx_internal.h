@@ -1,0 +1,61 @@
+// lpx_internal.h -- shared between the HIP kernels and the host-side C ABI of liblpx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/lpx.h"
+
+namespace lpx {
+
+// Device-resident loop state: one instance per tableau handle, written only by the select kernel.
+struct DevState {
+    int status;          // LPX_RUNNING until a terminal status is reached
+    int iter;            // pivots completed (index of the next trace slot)
+    int r, q;            // pivot chosen by the last select launch (r < 0: nothing to update)
+    int phase;           // 0 = ForceDualFeasibility, 1 = dual loop, 2 = primal loop
+    int fdf_count;       // pivots done in phase 0
+    int dual_iter;       // pivots done in phase 1
+    int primal_count;    // pivots done in phase 2
+    int forced_k;        // next entry of the forced-pivot list
+    int pad[7];
+};
+
+enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
+
+struct SelParams {
+    double* T; int ld; int R; int C;
+    double* prow;        // [ld]  normalised pivot row  T[r,:]/T[r,q]
+    double* pcol;        // [R]   pivot column snapshot T[:,q]
+    int32_t* basis;      // [R-1]
+    int32_t* trace;      // [2*trace_cap]
+    int trace_cap;
+    DevState* st;
+    double eps;          // Eps
+    double tol_fdf;      // ratio hysteresis in phase 0
+    double tol_dual;     // ratio hysteresis in phase 1
+    double tol_primal;   // ratio hysteresis in phase 2
+    int max_iter, fdf_guard, cleanup, mode;
+    const int32_t* frows; const int32_t* fcols; int fcount; double fthresh; int32_t* fchosen;
+    double* ws;          // [max(R,C)] global scratch for ratios when they do not fit LDS
+    int rcap;            // doubles of dynamic LDS available for ratios (0 = use ws)
+};
+
+// launchers (lpx_kernels.hip)
+hipError_t launch_select(const SelParams& p, hipStream_t s);
+hipError_t launch_update(double* T, int ld, int R, const double* prow, const double* pcol,
+                         const DevState* st, hipStream_t s);
+hipError_t kernels_init();          // one-time function attributes
+int select_lds_doubles();           // capacity of the dynamic LDS ratio buffer
+
+void set_error(const std::string& msg);
+
+}  // namespace lpx
+
+#define LPX_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            lpx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));             \
+            return LPX_EDEVICE;                                                            \
+        }                                                                                  \
+    } while (0)

@@ -1,0 +1,390 @@
+// lpx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the dense-tableau simplex loop.
+//
+// Built with -ffp-contract=off: `t - f*p` must round twice (v_mul_f64 + v_add_f64), exactly as the
+// reference's scalar C# does (Models/PrimalSimplex.cs:255); pivot-row normalisation uses true IEEE
+// division (Models/PrimalSimplex.cs:250), never a reciprocal multiply.
+//
+// Two launches per pivot on one stream:
+//   lpx_select  (1 workgroup x 1024 lanes)  ChooseEntering + ChooseLeaving + pivot prep
+//   lpx_update  (>> 256 workgroups)         rank-1 update of the whole tableau, HBM-bound
+#include "lpx_internal.h"
+#include <limits.h>
+
+namespace lpx {
+
+static constexpr int SEL_NT = 1024;          // lanes of the select workgroup
+static constexpr int SEL_NW = SEL_NT / 64;   // waves
+static constexpr int LIST_CAP = 2048;        // prefix-minimum records kept in LDS
+static constexpr int SEL_LDS_DOUBLES = 16384;// 128 KiB of dynamic LDS for ratios
+
+// ------------------------------------------------------------------------------------------------
+// workgroup primitives (wave64)
+// ------------------------------------------------------------------------------------------------
+struct MinIdx { double v; int i; };
+
+__device__ __forceinline__ MinIdx mi_pick(MinIdx a, MinIdx b)
+{
+    // strict minimum, lowest index on equal values ("first index of the strict minimum")
+    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+__device__ __forceinline__ MinIdx wave_min_idx(MinIdx x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        MinIdx y;
+        y.v = __shfl_xor(x.v, d, 64);
+        y.i = __shfl_xor(x.i, d, 64);
+        x = mi_pick(x, y);
+    }
+    return x;
+}
+
+// All SEL_NT lanes call this. Returns the block-wide winner in every lane.
+__device__ MinIdx block_min_idx(MinIdx x, double* s_v, int* s_i)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x = wave_min_idx(x);
+    __syncthreads();                     // protect s_v/s_i reuse
+    if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
+    __syncthreads();
+    MinIdx y;
+    y.v = s_v[lane & (SEL_NW - 1)];
+    y.i = s_i[lane & (SEL_NW - 1)];
+    y = wave_min_idx(y);
+    return y;
+}
+
+// exclusive prefix-minimum over lanes in thread order; identity = +inf
+__device__ double block_excl_scan_min(double x, double* s_v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double y = __shfl_up(inc, d, 64);
+        if (lane >= d && y < inc) inc = y;
+    }
+    __syncthreads();
+    if (lane == 63) s_v[wave] = inc;
+    __syncthreads();
+    double pre = __builtin_inf();        // minimum over all earlier waves
+    for (int w = 0; w < wave; ++w) { double y = s_v[w]; if (y < pre) pre = y; }
+    double up = __shfl_up(inc, 1, 64);   // minimum over earlier lanes of this wave
+    if (lane == 0) up = __builtin_inf();
+    return up < pre ? up : pre;
+}
+
+// exclusive prefix-sum over lanes in thread order; *total receives the block sum
+__device__ int block_excl_scan_sum(int x, int* s_i, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_i[wave] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int w = 0; w < SEL_NW; ++w) { int y = s_i[w]; if (w < wave) pre += y; tot += y; }
+    *total = tot;
+    return pre + inc - x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's ratio scans are NOT argmins: `if (ratio < best - tol) { best = ratio; row = i; }`
+// (Models/PrimalSimplex.cs:229-241, Models/DualSimplex.cs:79-91,:214-222) is a sequential hysteresis
+// chain.  Exact parallel form: a candidate can only be accepted if it is a strict prefix-minimum
+// record (accepted => ratio < fl(best - tol) <= min of all earlier ratios, because best never
+// exceeds fl(prefix_min + tol) ... see DESIGN.md "hysteresis scan").  So: ratios -> LDS, exclusive
+// prefix-min scan, compact the records in order, and one lane replays the chain over the (few)
+// records.  Falls back to a plain sequential replay when the record list overflows.
+// ratio(k) must return +inf for ineligible entries.
+// ------------------------------------------------------------------------------------------------
+template <class RatioFn>
+__device__ int block_hysteresis_argmin(int L, double tol, RatioFn ratio, double* rbuf,
+                                       int* s_list, double* s_v, int* s_i, int* s_out)
+{
+    const int t = threadIdx.x;
+    const int per = (L + SEL_NT - 1) / SEL_NT;
+    const int lo = t * per;
+    const int hi = (lo + per < L) ? lo + per : L;
+    double lmin = __builtin_inf();
+    for (int k = lo; k < hi; ++k) {
+        double r = ratio(k);
+        rbuf[k] = r;
+        if (r < lmin) lmin = r;
+    }
+    const double pre = block_excl_scan_min(lmin, s_v);
+    int cnt = 0;
+    double run = pre;
+    for (int k = lo; k < hi; ++k) {
+        double r = rbuf[k];
+        if (r < run) { ++cnt; run = r; }
+    }
+    int total;
+    int pos = block_excl_scan_sum(cnt, s_i, &total);
+    if (total <= LIST_CAP) {
+        run = pre;
+        for (int k = lo; k < hi; ++k) {
+            double r = rbuf[k];
+            if (r < run) { s_list[pos++] = k; run = r; }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        double best = __builtin_inf();
+        int win = -1;
+        if (total <= LIST_CAP) {
+            for (int e = 0; e < total; ++e) {
+                int k = s_list[e];
+                double r = rbuf[k];
+                if (r < best - tol) { best = r; win = k; }
+            }
+        } else {
+            for (int k = 0; k < L; ++k) {
+                double r = rbuf[k];
+                if (r < best - tol) { best = r; win = k; }
+            }
+        }
+        *s_out = win;
+    }
+    __syncthreads();
+    return *s_out;
+}
+
+// ChooseEntering, Models/PrimalSimplex.cs:205-220: first index of the strict minimum of `v[0..L)`
+// (stride `stride`) below -eps, else -1.  Also used for the dual loop's leaving row (most negative
+// RHS, Models/DualSimplex.cs:45-55).
+__device__ int block_first_min_below(const double* v, size_t stride, int L, double eps,
+                                     double* s_v, int* s_i)
+{
+    MinIdx m; m.v = -eps; m.i = INT_MAX;
+    for (int j = threadIdx.x; j < L; j += SEL_NT) {
+        double x = v[(size_t)j * stride];
+        if (x < m.v) { m.v = x; m.i = j; }
+    }
+    m = block_min_idx(m, s_v, s_i);
+    return m.i == INT_MAX ? -1 : m.i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lpx_select: one workgroup decides the next pivot and prepares the update's operands.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
+{
+    extern __shared__ __align__(16) double s_dyn[];
+    __shared__ int s_list[LIST_CAP];
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    __shared__ int s_out;
+    __shared__ double s_piv;
+
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;              // uniform: loop already finished
+
+    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
+    const int t = threadIdx.x;
+    const int m = P.R - 1;
+    const int rhs = P.C - 1;
+    const size_t ld = (size_t)P.ld;
+    double* T = P.T;
+
+    int phase = st->phase;
+    const int fdf_count = st->fdf_count, dual_iter = st->dual_iter, primal_count = st->primal_count;
+    const int iter = st->iter;
+    int r = -1, q = -1;
+    int final_status = LPX_RUNNING;
+
+    if (P.mode == MODE_FORCED) {
+        const int k = st->forced_k;
+        if (k >= P.fcount) {
+            final_status = LPX_OPTIMAL;
+        } else {
+            r = P.frows[k];
+            const int c0 = P.fcols[k];
+            MinIdx mi; mi.v = 0.0; mi.i = INT_MAX;     // minimise the wrapped offset
+            for (int j = t; j < P.C; j += SEL_NT) {
+                if (fabs(T[(size_t)r * ld + j]) >= P.fthresh) {
+                    int off = j - c0; if (off < 0) off += P.C;
+                    if (off < mi.i) mi.i = off;
+                }
+            }
+            mi = block_min_idx(mi, s_v, s_i);
+            if (mi.i == INT_MAX) q = -1;
+            else { q = c0 + mi.i; if (q >= P.C) q -= P.C; }
+            if (t == 0) { P.fchosen[k] = q; st->forced_k = k + 1; }
+            if (q < 0) { if (t == 0) { st->r = -1; st->q = -1; } return; }
+        }
+    } else {
+        // state machine: ForceDualFeasibility -> dual loop -> (repaired mode) primal clean-up
+        for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0; ++hop) {
+            if (phase == 0) {
+                // ForceDualFeasibility, Models/DualSimplex.cs:195-228
+                if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
+                q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
+                if (q < 0) { phase = 1; continue; }
+                const int qq = q; const double eps = P.eps;
+                r = block_hysteresis_argmin(m, P.tol_fdf, [&](int i) {
+                        double a = T[(size_t)i * ld + qq];
+                        return a > eps ? T[(size_t)i * ld + rhs] / a : __builtin_inf(); },
+                    rbuf, s_list, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; phase = 1; continue; }
+            } else if (phase == 1) {
+                // dual loop, Models/DualSimplex.cs:36-113
+                if (dual_iter >= P.max_iter) { final_status = LPX_ITER_LIMIT; break; }
+                r = block_first_min_below(T + rhs, ld, m, P.eps, s_v, s_i);
+                if (r < 0) {
+                    if (P.cleanup) {
+                        int qe = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
+                        if (qe >= 0) { phase = 2; continue; }
+                    }
+                    final_status = LPX_OPTIMAL; break;
+                }
+                const int rr = r; const double eps = P.eps;
+                q = block_hysteresis_argmin(rhs, P.tol_dual, [&](int j) {
+                        double a = T[(size_t)rr * ld + j];
+                        return a < -eps ? T[(size_t)m * ld + j] / (-a) : __builtin_inf(); },
+                    rbuf, s_list, s_v, s_i, &s_out);
+                if (q < 0) { r = -1; final_status = LPX_INFEASIBLE; break; }
+            } else {
+                // primal loop, Models/PrimalSimplex.cs:92-124
+                if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
+                q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
+                if (q < 0) { final_status = LPX_OPTIMAL; break; }
+                const int qq = q; const double eps = P.eps;
+                r = block_hysteresis_argmin(m, P.tol_primal, [&](int i) {
+                        double a = T[(size_t)i * ld + qq];
+                        return a > eps ? T[(size_t)i * ld + rhs] / a : __builtin_inf(); },
+                    rbuf, s_list, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
+            }
+        }
+    }
+
+    if (final_status != LPX_RUNNING || r < 0) {
+        if (t == 0) {
+            st->status = (final_status == LPX_RUNNING) ? LPX_OPTIMAL : final_status;
+            st->phase = phase; st->r = -1; st->q = -1;
+        }
+        return;
+    }
+
+    // ---- pivot prep (Models/PrimalSimplex.cs:249-250, :254): snapshot the pivot column, normalise
+    // the pivot row in place and into `prow` so the update kernel never reads what it overwrites.
+    if (t == 0) s_piv = T[(size_t)r * ld + q];
+    __syncthreads();
+    const double piv = s_piv;
+    for (int i = t; i < P.R; i += SEL_NT)
+        P.pcol[i] = (i == r) ? 0.0 : T[(size_t)i * ld + q];
+    __syncthreads();                                   // column read before the row is rewritten
+    double* trow = T + (size_t)r * ld;
+    for (int j = t; j < P.C; j += SEL_NT) {
+        double p = trow[j] / piv;
+        trow[j] = p;
+        P.prow[j] = p;
+    }
+    if (t == 0) {
+        if (P.mode != MODE_FORCED) P.basis[r] = q;     // basis[leaving] = entering, :110
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        st->iter = iter + 1;
+        st->r = r; st->q = q; st->phase = phase;
+        if (P.mode != MODE_FORCED) {
+            if (phase == 0) st->fdf_count = fdf_count + 1;
+            else if (phase == 1) st->dual_iter = dual_iter + 1;
+            else st->primal_count = primal_count + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lpx_update: T[i, :] -= pcol[i] * prow[:] for every row i != r  (Models/PrimalSimplex.cs:251-256,
+// Models/DualSimplex.cs:240-245).  HBM-bound: 16 bytes of traffic per element, 2 flop.
+//
+// Work unit = one wave x (128 columns x UPD_ROWS rows): each lane owns two adjacent doubles
+// (one 16-byte global_load_dwordx4 / global_store_dwordx4 per row, 1 KiB contiguous per wave per
+// row), keeps its slice of the normalised pivot row in registers, takes the row factor from a
+// scalar load, and has UPD_ROWS independent loads in flight.  Units are flattened over
+// (row block, column chunk) so ragged widths waste at most part of one wave per row block.
+// ------------------------------------------------------------------------------------------------
+static constexpr int UPD_NT = 256;
+static constexpr int UPD_ROWS = 8;
+
+__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int R,
+                                                     const double* __restrict__ prow,
+                                                     const double* __restrict__ pcol,
+                                                     const DevState* __restrict__ st,
+                                                     int ncw, int nunits)
+{
+    if (st->status != LPX_RUNNING) return;
+    const int r = st->r;
+    if (r < 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    if (unit >= nunits) return;
+    const int cw = unit % ncw;
+    const int rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    if (col >= ld) return;                      // ld is a multiple of 16, so col+1 < ld too
+    const double2 p = *reinterpret_cast<const double2*>(prow + col);
+    const int row0 = rb * UPD_ROWS;
+    double* base = T + (size_t)row0 * ld + col;
+
+    double2 v[UPD_ROWS];
+    double f[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R) {
+            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+            f[k] = pcol[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R && i != r) {
+            double2 o;
+            o.x = v[k].x - f[k] * p.x;          // mul, then sub: contraction is off
+            o.y = v[k].y - f[k] * p.y;
+            *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int select_lds_doubles() { return SEL_LDS_DOUBLES; }
+
+hipError_t kernels_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SEL_LDS_DOUBLES * (int)sizeof(double));
+}
+
+hipError_t launch_select(const SelParams& p, hipStream_t s)
+{
+    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
+    hipLaunchKernelGGL(lpx_select, dim3(1), dim3(SEL_NT), dyn, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_update(double* T, int ld, int R, const double* prow, const double* pcol,
+                         const DevState* st, hipStream_t s)
+{
+    const int ncw = (ld + 127) / 128;
+    const int nrb = (R + UPD_ROWS - 1) / UPD_ROWS;
+    const int nunits = ncw * nrb;
+    const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
+    hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s, T, ld, R, prow, pcol, st, ncw, nunits);
+    return hipGetLastError();
+}
+
+}  // namespace lpx

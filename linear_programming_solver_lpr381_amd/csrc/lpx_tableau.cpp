@@ -1,0 +1,497 @@
+// lpx_tableau.cpp -- device-resident tableau handle and the host side of the simplex loops
+// (C ABI of include/lpx.h).  Host code only: kernels live in lpx_kernels.hip.
+#include "lpx_internal.h"
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace lpx {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static std::once_flag g_init_once;
+static hipError_t g_init_err = hipSuccess;
+static int g_device = -1;
+
+static int ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (liblpx has no CPU fallback)");
+        return LPX_EDEVICE;
+    }
+    if (g_device < 0) {
+        g_device = 0;
+        LPX_HIP_TRY(hipSetDevice(0));
+    }
+    std::call_once(g_init_once, [] { g_init_err = kernels_init(); });
+    if (g_init_err != hipSuccess) {
+        set_error(std::string("kernel attribute setup failed: ") + hipGetErrorString(g_init_err));
+        return LPX_EDEVICE;
+    }
+    return 0;
+}
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace lpx
+
+using namespace lpx;
+
+struct lpx_tableau {
+    int R = 0, C = 0, ld = 0;
+    double* T = nullptr;        // [R*ld]
+    double* snapT = nullptr;    // snapshot
+    double* prow = nullptr;     // [ld]
+    double* pcol = nullptr;     // [R]
+    double* ws = nullptr;       // [max(R,C)]
+    int32_t* basis = nullptr;   // [R-1]
+    int32_t* snapBasis = nullptr;
+    int32_t* trace = nullptr;   // [2*trace_cap]
+    int trace_cap = 0;
+    DevState* st = nullptr;     // device
+    DevState* hst = nullptr;    // pinned host mirror
+    int32_t* frows = nullptr; int32_t* fcols = nullptr; int32_t* fchosen = nullptr; int fcap = 0;
+    hipStream_t stream = nullptr;
+    // cached graph of `g_batch` (select, update) pairs
+    hipGraphExec_t gexec = nullptr;
+    int g_batch = 0;
+    SelParams g_params{};
+    std::vector<hipEvent_t> events;
+};
+
+static void drop_graph(lpx_tableau* t)
+{
+    if (t->gexec) { hipGraphExecDestroy(t->gexec); t->gexec = nullptr; t->g_batch = 0; }
+}
+
+extern "C" {
+
+int lpx_abi_version(void) { return LPX_ABI_VERSION; }
+
+int lpx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lpx_init(int device)
+{
+    int n = lpx_device_count();
+    if (device < 0 || device >= n) { set_error("lpx_init: device index out of range"); return LPX_EDEVICE; }
+    LPX_HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return ensure_device();
+}
+
+int lpx_last_error(char* buf, int len)
+{
+    if (!buf || len <= 0) return (int)g_err.size();
+    std::strncpy(buf, g_err.c_str(), len - 1);
+    buf[len - 1] = 0;
+    return (int)g_err.size();
+}
+
+int lpx_device_name(char* buf, int len)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    LPX_HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    std::snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+void lpx_default_opts(lpx_run_opts* o, int dual)
+{
+    std::memset(o, 0, sizeof(*o));
+    o->eps = 1e-9;
+    o->ratio_tol = dual ? 1e-12 : 1e-9;
+    o->max_iter = 10000;
+    o->fdf_guard = 100;
+    o->cleanup = 0;
+    o->batch = 0;
+    o->use_graph = 1;
+    o->profile = 0;
+}
+
+int lpx_tableau_create(int R, int C, lpx_tableau** out)
+{
+    if (!out || R < 1 || C < 2) { set_error("lpx_tableau_create: bad shape"); return LPX_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    lpx_tableau* t = new lpx_tableau();
+    t->R = R; t->C = C; t->ld = (C + 15) / 16 * 16;
+    const size_t tb = sizeof(double) * (size_t)R * t->ld;
+    const int wsn = R > C ? R : C;
+    t->trace_cap = 1 << 16;
+#define ALLOC(ptr, bytes)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                   \
+        if (e_ != hipSuccess) {                                                               \
+            set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_));             \
+            lpx_tableau_destroy(t);                                                           \
+            return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE;                      \
+        }                                                                                     \
+    } while (0)
+    ALLOC(t->T, tb);
+    ALLOC(t->prow, sizeof(double) * t->ld);
+    ALLOC(t->pcol, sizeof(double) * R);
+    ALLOC(t->ws, sizeof(double) * wsn);
+    ALLOC(t->basis, sizeof(int32_t) * (R > 1 ? R - 1 : 1));
+    ALLOC(t->trace, sizeof(int32_t) * 2 * t->trace_cap);
+    ALLOC(t->st, sizeof(DevState));
+#undef ALLOC
+    if (hipHostMalloc((void**)&t->hst, sizeof(DevState)) != hipSuccess ||
+        hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("host-pinned state / stream creation failed");
+        lpx_tableau_destroy(t);
+        return LPX_EDEVICE;
+    }
+    hipMemsetAsync(t->T, 0, tb, t->stream);
+    hipMemsetAsync(t->prow, 0, sizeof(double) * t->ld, t->stream);
+    hipMemsetAsync(t->pcol, 0, sizeof(double) * R, t->stream);
+    hipMemsetAsync(t->basis, 0, sizeof(int32_t) * (R > 1 ? R - 1 : 1), t->stream);
+    hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream);
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    *out = t;
+    return 0;
+}
+
+void lpx_tableau_destroy(lpx_tableau* t)
+{
+    if (!t) return;
+    if (t->stream) hipStreamSynchronize(t->stream);
+    drop_graph(t);
+    for (hipEvent_t e : t->events) hipEventDestroy(e);
+    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->ws);
+    hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
+    hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen);
+    if (t->hst) hipHostFree(t->hst);
+    if (t->stream) hipStreamDestroy(t->stream);
+    delete t;
+}
+
+int lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld)
+{
+    if (!t) return LPX_EINVAL;
+    if (R) *R = t->R;
+    if (C) *C = t->C;
+    if (ld) *ld = t->ld;
+    return 0;
+}
+
+int lpx_tableau_upload(lpx_tableau* t, const double* T, const int32_t* basis)
+{
+    if (!t || !T) { set_error("lpx_tableau_upload: null argument"); return LPX_EINVAL; }
+    LPX_HIP_TRY(hipMemcpy2DAsync(t->T, sizeof(double) * t->ld, T, sizeof(double) * t->C,
+                                 sizeof(double) * t->C, t->R, hipMemcpyHostToDevice, t->stream));
+    if (basis && t->R > 1)
+        LPX_HIP_TRY(hipMemcpyAsync(t->basis, basis, sizeof(int32_t) * (t->R - 1), hipMemcpyHostToDevice, t->stream));
+    LPX_HIP_TRY(hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int lpx_tableau_download(lpx_tableau* t, double* T, int32_t* basis)
+{
+    if (!t) return LPX_EINVAL;
+    if (T)
+        LPX_HIP_TRY(hipMemcpy2DAsync(T, sizeof(double) * t->C, t->T, sizeof(double) * t->ld,
+                                     sizeof(double) * t->C, t->R, hipMemcpyDeviceToHost, t->stream));
+    if (basis && t->R > 1)
+        LPX_HIP_TRY(hipMemcpyAsync(basis, t->basis, sizeof(int32_t) * (t->R - 1), hipMemcpyDeviceToHost, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int lpx_tableau_snapshot(lpx_tableau* t)
+{
+    if (!t) return LPX_EINVAL;
+    const size_t tb = sizeof(double) * (size_t)t->R * t->ld;
+    if (!t->snapT) {
+        LPX_HIP_TRY(hipMalloc((void**)&t->snapT, tb));
+        LPX_HIP_TRY(hipMalloc((void**)&t->snapBasis, sizeof(int32_t) * (t->R > 1 ? t->R - 1 : 1)));
+    }
+    LPX_HIP_TRY(hipMemcpyAsync(t->snapT, t->T, tb, hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipMemcpyAsync(t->snapBasis, t->basis, sizeof(int32_t) * (t->R > 1 ? t->R - 1 : 1),
+                               hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int lpx_tableau_restore(lpx_tableau* t)
+{
+    if (!t || !t->snapT) { set_error("lpx_tableau_restore: no snapshot"); return LPX_EINVAL; }
+    const size_t tb = sizeof(double) * (size_t)t->R * t->ld;
+    LPX_HIP_TRY(hipMemcpyAsync(t->T, t->snapT, tb, hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipMemcpyAsync(t->basis, t->snapBasis, sizeof(int32_t) * (t->R > 1 ? t->R - 1 : 1),
+                               hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
+{
+    if (!t) return LPX_EINVAL;
+    if (dptr) *dptr = t->T;
+    if (ld) *ld = t->ld;
+    return 0;
+}
+
+int lpx_tableau_trace(lpx_tableau* t, int32_t* trace, int cap, int* n)
+{
+    if (!t) return LPX_EINVAL;
+    LPX_HIP_TRY(hipMemcpyAsync(t->hst, t->st, sizeof(DevState), hipMemcpyDeviceToHost, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    int k = t->hst->iter;
+    if (k > t->trace_cap) k = t->trace_cap;
+    if (n) *n = k;
+    if (trace && cap > 0) {
+        int c = k < cap ? k : cap;
+        if (c > 0) LPX_HIP_TRY(hipMemcpy(trace, t->trace, sizeof(int32_t) * 2 * c, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// the loop driver
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+bool same_params(const SelParams& a, const SelParams& b) { return std::memcmp(&a, &b, sizeof(SelParams)) == 0; }
+
+int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s)
+{
+    LPX_HIP_TRY(launch_select(p, s));
+    LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->prow, t->pcol, t->st, s));
+    return 0;
+}
+
+int build_graph(lpx_tableau* t, const SelParams& p, int batch)
+{
+    if (t->gexec && t->g_batch == batch && same_params(t->g_params, p)) return 0;
+    drop_graph(t);
+    hipGraph_t graph = nullptr;
+    LPX_HIP_TRY(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < batch; ++i) {
+        int rc = enqueue_pair(t, p, t->stream);
+        if (rc) { hipStreamEndCapture(t->stream, &graph); if (graph) hipGraphDestroy(graph); return rc; }
+    }
+    LPX_HIP_TRY(hipStreamEndCapture(t->stream, &graph));
+    hipError_t e = hipGraphInstantiate(&t->gexec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { t->gexec = nullptr; set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return LPX_EDEVICE; }
+    t->g_batch = batch;
+    t->g_params = p;
+    return 0;
+}
+
+// Runs select/update pairs until the device state leaves LPX_RUNNING.  `budget` bounds the number
+// of pairs ever enqueued (each pair either pivots, changes phase, or terminates).
+int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budget,
+             lpx_pivot_cb cb, void* user, lpx_stats* stats)
+{
+    int batch = o->batch > 0 ? o->batch : 64;
+    if (o->profile && batch > 256) batch = 256;
+    const bool graph = o->use_graph && !o->profile;
+    lpx_stats local; std::memset(&local, 0, sizeof(local));
+
+    // reset loop state (tableau and basis stay)
+    DevState init; std::memset(&init, 0, sizeof(init));
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1;
+    init.phase = (p.mode == MODE_DUAL) ? 0 : 2;
+    LPX_HIP_TRY(hipMemcpyAsync(t->st, &init, sizeof(init), hipMemcpyHostToDevice, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+
+    if (o->profile && (int)t->events.size() < 2 * batch) {
+        size_t need = 2 * (size_t)batch;
+        while (t->events.size() < need) {
+            hipEvent_t e;
+            LPX_HIP_TRY(hipEventCreate(&e));
+            t->events.push_back(e);
+        }
+    }
+    if (graph) { int rc = build_graph(t, p, batch); if (rc) return rc; }
+
+    const double t0 = now_ms();
+    int fired = 0;
+    long long enq = 0;
+    int status = LPX_RUNNING;
+    while (status == LPX_RUNNING && enq < budget) {
+        const int iter_before = fired;
+        if (graph) {
+            LPX_HIP_TRY(hipGraphLaunch(t->gexec, t->stream));
+        } else if (o->profile) {
+            for (int i = 0; i < batch; ++i) {
+                LPX_HIP_TRY(launch_select(p, t->stream));
+                LPX_HIP_TRY(hipEventRecord(t->events[2 * i], t->stream));
+                LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->prow, t->pcol, t->st, t->stream));
+                LPX_HIP_TRY(hipEventRecord(t->events[2 * i + 1], t->stream));
+            }
+        } else {
+            for (int i = 0; i < batch; ++i) { int rc = enqueue_pair(t, p, t->stream); if (rc) return rc; }
+        }
+        enq += batch;
+        local.launches += 2 * (long long)batch;
+        LPX_HIP_TRY(hipMemcpyAsync(t->hst, t->st, sizeof(DevState), hipMemcpyDeviceToHost, t->stream));
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        status = t->hst->status;
+        const int done = t->hst->iter;
+        if (o->profile) {
+            // every pair of this batch that completed a pivot ran a full update; in primal/forced
+            // mode those are exactly the first (done - iter_before) pairs of the batch.
+            int full = done - iter_before;
+            if (p.mode == MODE_DUAL) full = 0;       // phase hops make the mapping ambiguous: not profiled
+            for (int i = 0; i < full && i < batch; ++i) {
+                float ms = 0.f;
+                LPX_HIP_TRY(hipEventElapsedTime(&ms, t->events[2 * i], t->events[2 * i + 1]));
+                local.update_ms_sum += ms;
+                local.update_launches++;
+            }
+        }
+        if (cb && done > fired) {
+            std::vector<int32_t> tr(2 * (size_t)(done - fired));
+            int lo = fired, hi = done < t->trace_cap ? done : t->trace_cap;
+            if (hi > lo) {
+                LPX_HIP_TRY(hipMemcpy(tr.data(), t->trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
+                for (int k = lo; k < hi; ++k) cb(user, k + 1, tr[2 * (k - lo)], tr[2 * (k - lo) + 1]);
+            }
+        }
+        fired = done;
+    }
+    local.loop_ms = now_ms() - t0;
+    local.pivots = t->hst->iter;
+    local.fdf_pivots = t->hst->fdf_count;
+    local.cleanup_pivots = (p.mode == MODE_DUAL) ? t->hst->primal_count : 0;
+    if (stats) {
+        double h2d = stats->h2d_ms, d2h = stats->d2h_ms;
+        *stats = local; stats->h2d_ms = h2d; stats->d2h_ms = d2h;
+    }
+    if (status == LPX_RUNNING) { set_error("loop budget exhausted while still running"); return LPX_ITER_LIMIT; }
+    return status;
+}
+
+SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
+{
+    SelParams p; std::memset(&p, 0, sizeof(p));
+    p.T = t->T; p.ld = t->ld; p.R = t->R; p.C = t->C;
+    p.prow = t->prow; p.pcol = t->pcol; p.basis = t->basis; p.trace = t->trace; p.trace_cap = t->trace_cap;
+    p.st = t->st;
+    p.eps = o->eps;
+    p.tol_fdf = o->ratio_tol; p.tol_dual = o->ratio_tol;
+    p.tol_primal = (mode == MODE_DUAL) ? o->eps : o->ratio_tol;
+    p.max_iter = o->max_iter; p.fdf_guard = o->fdf_guard; p.cleanup = o->cleanup; p.mode = mode;
+    p.ws = t->ws;
+    const int need = t->R > t->C ? t->R : t->C;
+    p.rcap = need <= select_lds_doubles() ? need : 0;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    if (!t) { set_error("lpx_primal_run: null tableau"); return LPX_EINVAL; }
+    lpx_run_opts d; if (!o) { lpx_default_opts(&d, 0); o = &d; }
+    if (t->R < 2) { set_error("lpx_primal_run: tableau needs at least one constraint row"); return LPX_EINVAL; }
+    SelParams p = base_params(t, o, MODE_PRIMAL);
+    return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st);
+}
+
+int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    if (!t) { set_error("lpx_dual_run: null tableau"); return LPX_EINVAL; }
+    lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
+    if (t->R < 2) { set_error("lpx_dual_run: tableau needs at least one constraint row"); return LPX_EINVAL; }
+    SelParams p = base_params(t, o, MODE_DUAL);
+    long long budget = (long long)o->fdf_guard + 2LL * o->max_iter + 8;
+    return run_loop(t, p, o, budget, cb, user, st);
+}
+
+int lpx_forced_pivots_run(lpx_tableau* t, const int32_t* rows, const int32_t* cols, int count,
+                          double thresh, int32_t* chosen, const lpx_run_opts* o, lpx_stats* st)
+{
+    if (!t || !rows || !cols || count < 0) { set_error("lpx_forced_pivots_run: bad argument"); return LPX_EINVAL; }
+    lpx_run_opts d; if (!o) { lpx_default_opts(&d, 0); o = &d; }
+    for (int k = 0; k < count; ++k)
+        if (rows[k] < 0 || rows[k] >= t->R || cols[k] < 0 || cols[k] >= t->C) {
+            set_error("lpx_forced_pivots_run: pivot position outside the tableau"); return LPX_EINVAL;
+        }
+    if (count > t->fcap) {
+        hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen);
+        t->frows = t->fcols = t->fchosen = nullptr; t->fcap = 0;
+        LPX_HIP_TRY(hipMalloc((void**)&t->frows, sizeof(int32_t) * count));
+        LPX_HIP_TRY(hipMalloc((void**)&t->fcols, sizeof(int32_t) * count));
+        LPX_HIP_TRY(hipMalloc((void**)&t->fchosen, sizeof(int32_t) * count));
+        t->fcap = count;
+        drop_graph(t);
+    }
+    if (count > 0) {
+        LPX_HIP_TRY(hipMemcpyAsync(t->frows, rows, sizeof(int32_t) * count, hipMemcpyHostToDevice, t->stream));
+        LPX_HIP_TRY(hipMemcpyAsync(t->fcols, cols, sizeof(int32_t) * count, hipMemcpyHostToDevice, t->stream));
+        LPX_HIP_TRY(hipMemsetAsync(t->fchosen, 0xff, sizeof(int32_t) * count, t->stream));
+    }
+    SelParams p = base_params(t, o, MODE_FORCED);
+    p.frows = t->frows; p.fcols = t->fcols; p.fcount = count; p.fthresh = thresh; p.fchosen = t->fchosen;
+    int rc = run_loop(t, p, o, (long long)count + 2, nullptr, nullptr, st);
+    if (chosen && count > 0)
+        LPX_HIP_TRY(hipMemcpy(chosen, t->fchosen, sizeof(int32_t) * count, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+static int one_shot(double* T, int R, int C, int32_t* basis, const lpx_run_opts* o, int dual,
+                    lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    if (!T || !basis) { set_error("null tableau or basis"); return LPX_EINVAL; }
+    lpx_tableau* t = nullptr;
+    int rc = lpx_tableau_create(R, C, &t);
+    if (rc) return rc;
+    double a = now_ms();
+    rc = lpx_tableau_upload(t, T, basis);
+    double h2d = now_ms() - a;
+    if (rc) { lpx_tableau_destroy(t); return rc; }
+    lpx_stats local; std::memset(&local, 0, sizeof(local));
+    int status = dual ? lpx_dual_run(t, o, cb, user, &local) : lpx_primal_run(t, o, cb, user, &local);
+    if (status < 0) { lpx_tableau_destroy(t); return status; }
+    a = now_ms();
+    rc = lpx_tableau_download(t, T, basis);
+    local.d2h_ms = now_ms() - a;
+    local.h2d_ms = h2d;
+    lpx_tableau_destroy(t);
+    if (st) *st = local;
+    return rc ? rc : status;
+}
+
+int lpx_primal_tableau(double* T, int R, int C, int32_t* basis, double eps, int max_iter,
+                       lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    lpx_run_opts o; lpx_default_opts(&o, 0);
+    o.eps = eps; o.ratio_tol = eps; o.max_iter = max_iter;
+    return one_shot(T, R, C, basis, &o, 0, cb, user, st);
+}
+
+int lpx_dual_tableau(double* T, int R, int C, int32_t* basis, double eps, double ratio_tol,
+                     int fdf_guard, int max_iter, int cleanup,
+                     lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    lpx_run_opts o; lpx_default_opts(&o, 1);
+    o.eps = eps; o.ratio_tol = ratio_tol; o.fdf_guard = fdf_guard; o.max_iter = max_iter; o.cleanup = cleanup;
+    return one_shot(T, R, C, basis, &o, 1, cb, user, st);
+}
+
+}  // extern "C"
