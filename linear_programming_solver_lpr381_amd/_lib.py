@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblpx.so")
+# LPX_LIB_PATH: diagnostic builds only (e.g. the -DLPX_STAMPS library of tools/diag_select_stamps.py)
+LIB_PATH = os.environ.get("LPX_LIB_PATH") or os.path.join(_PKG, "liblpx.so")
 
 # status / error codes (include/lpx.h)
 OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, RUNNING = 0, 1, 2, 3, 4

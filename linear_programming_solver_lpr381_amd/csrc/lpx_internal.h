@@ -17,7 +17,8 @@ struct DevState {
     int dual_iter;       // pivots done in phase 1
     int primal_count;    // pivots done in phase 2
     int forced_k;        // next entry of the forced-pivot list
-    int pad[7];
+    int qn;              // lookahead: entering column of the NEXT pivot (-1 = none), see lpx_select_la
+    int pad[6];
 };
 
 enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
@@ -25,7 +26,10 @@ enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
 struct SelParams {
     double* T; int ld; int R; int C;
     double* prow;        // [ld]  normalised pivot row  T[r,:]/T[r,q]
-    double* pcol;        // [R]   pivot column snapshot T[:,q]
+    double* pcol;        // [R]   pivot column snapshot T[:,q]        (dual path)
+    double* col0;        // [R]   lookahead column buffers, ping-pong   (primal / forced path)
+    double* col1;
+    double* rhsbuf;      // [R]   contiguous copy of the RHS column
     int32_t* basis;      // [R-1]
     int32_t* trace;      // [2*trace_cap]
     int trace_cap;
@@ -41,9 +45,14 @@ struct SelParams {
 };
 
 // launchers (lpx_kernels.hip)
-hipError_t launch_select(const SelParams& p, hipStream_t s);
-hipError_t launch_update(double* T, int ld, int R, const double* prow, const double* pcol,
-                         const DevState* st, hipStream_t s);
+hipError_t launch_select(const SelParams& p, hipStream_t s);       // gather-based (dual path)
+hipError_t launch_select_la(const SelParams& p, hipStream_t s);    // lookahead (primal / forced)
+hipError_t launch_la_init(const SelParams& p, hipStream_t s);
+// fac0/fac1: factor columns, chosen by pivot parity; nxt by-products go to the other one.
+// e0/e1 non-null: bracket the dispatch with HIP events bound to the kernel (hipExtLaunchKernelGGL).
+hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, double* fac0, double* fac1,
+                         double* rhsbuf, const DevState* st, hipStream_t s,
+                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t kernels_init();          // one-time function attributes
 int select_lds_doubles();           // capacity of the dynamic LDS ratio buffer
 

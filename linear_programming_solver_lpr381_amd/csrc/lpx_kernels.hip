@@ -8,6 +8,7 @@
 //   lpx_select  (1 workgroup x 1024 lanes)  ChooseEntering + ChooseLeaving + pivot prep
 //   lpx_update  (>> 256 workgroups)         rank-1 update of the whole tableau, HBM-bound
 #include "lpx_internal.h"
+#include <hip/hip_ext.h>
 #include <limits.h>
 
 namespace lpx {
@@ -200,27 +201,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
     int r = -1, q = -1;
     int final_status = LPX_RUNNING;
 
-    if (P.mode == MODE_FORCED) {
-        const int k = st->forced_k;
-        if (k >= P.fcount) {
-            final_status = LPX_OPTIMAL;
-        } else {
-            r = P.frows[k];
-            const int c0 = P.fcols[k];
-            MinIdx mi; mi.v = 0.0; mi.i = INT_MAX;     // minimise the wrapped offset
-            for (int j = t; j < P.C; j += SEL_NT) {
-                if (fabs(T[(size_t)r * ld + j]) >= P.fthresh) {
-                    int off = j - c0; if (off < 0) off += P.C;
-                    if (off < mi.i) mi.i = off;
-                }
-            }
-            mi = block_min_idx(mi, s_v, s_i);
-            if (mi.i == INT_MAX) q = -1;
-            else { q = c0 + mi.i; if (q >= P.C) q -= P.C; }
-            if (t == 0) { P.fchosen[k] = q; st->forced_k = k + 1; }
-            if (q < 0) { if (t == 0) { st->r = -1; st->q = -1; } return; }
-        }
-    } else {
+    {
         // state machine: ForceDualFeasibility -> dual loop -> (repaired mode) primal clean-up
         for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0; ++hop) {
             if (phase == 0) {
@@ -289,16 +270,204 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
         P.prow[j] = p;
     }
     if (t == 0) {
-        if (P.mode != MODE_FORCED) P.basis[r] = q;     // basis[leaving] = entering, :110
+        P.basis[r] = q;                                // basis[leaving] = entering, :110
         if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
         st->iter = iter + 1;
-        st->r = r; st->q = q; st->phase = phase;
-        if (P.mode != MODE_FORCED) {
-            if (phase == 0) st->fdf_count = fdf_count + 1;
-            else if (phase == 1) st->dual_iter = dual_iter + 1;
-            else st->primal_count = primal_count + 1;
+        st->r = r; st->q = q; st->phase = phase; st->qn = -1;
+        if (phase == 0) st->fdf_count = fdf_count + 1;
+        else if (phase == 1) st->dual_iter = dual_iter + 1;
+        else st->primal_count = primal_count + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lookahead select (primal and forced-pivot paths).
+//
+// The gather-based select above spends most of its time in 64-cache-lines-per-instruction strided
+// column reads on ONE CU.  Here the update kernel of pivot k writes, as by-products of the stream it
+// already does, the column that pivot k+1 will enter on (`coln`) and the RHS column (`rhsbuf`), both
+// contiguous.  That is possible because the entering column of pivot k+1 depends only on the
+// objective row AFTER pivot k, which select(k) can compute itself (obj - f_m * prow, the very
+// arithmetic the update kernel will repeat bit for bit).  So select(k):
+//   ratio test on contiguous colc/rhsbuf  ->  r
+//   normalise row r (contiguous)          ->  prow, T[r,:]
+//   updated scan row u = T[s,:] - colc[s]*prow  ->  next entering column qn   (s = objective row;
+//   forced mode: s = next forced row, rule = first |u| >= thresh from the next forced column)
+// Column buffers ping-pong on pivot parity: update(k) reads colc as factors while writing coln.
+// ------------------------------------------------------------------------------------------------
+struct ScanRule { int forced; double eps; double thresh; int c0; int C; };
+
+#ifdef LPX_STAMPS
+// Diagnostic build only (never shipped): thread 0 accumulates s_memtime deltas per segment into ws[].
+#define LPX_STAMP(slot)                                                                        \
+    do { if (threadIdx.x == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+         reinterpret_cast<unsigned long long*>(P.ws)[(slot)] += now_ - stamp_prev_; stamp_prev_ = now_; } } while (0)
+#define LPX_STAMP_BEGIN unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime(); \
+    unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#define LPX_STAMP_END do { if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(P.ws)[14] += __builtin_amdgcn_s_memrealtime() - rt0_; \
+    reinterpret_cast<unsigned long long*>(P.ws)[15] += 1; } } while (0)
+#else
+#define LPX_STAMP(slot) do {} while (0)
+#define LPX_STAMP_BEGIN
+#define LPX_STAMP_END do {} while (0)
+#endif
+
+__device__ __forceinline__ void rule_init(const ScanRule& R, MinIdx& m)
+{
+    m.v = R.forced ? 0.0 : -R.eps; m.i = INT_MAX;
+}
+__device__ __forceinline__ void rule_feed(const ScanRule& R, MinIdx& m, int j, double u)
+{
+    if (R.forced) {
+        if (fabs(u) >= R.thresh) { int off = j - R.c0; if (off < 0) off += R.C; if (off < m.i) m.i = off; }
+    } else {
+        if (j < R.C - 1 && u < m.v) { m.v = u; m.i = j; }      // ChooseEntering, :205-220
+    }
+}
+__device__ __forceinline__ int rule_decode(const ScanRule& R, const MinIdx& m)
+{
+    if (m.i == INT_MAX) return -1;
+    if (!R.forced) return m.i;
+    int q = R.c0 + m.i; if (q >= R.C) q -= R.C;
+    return q;
+}
+
+// Slow path (once per solve, or after a skipped forced pivot): pick the next column from T as it
+// stands and gather it plus the RHS column with strided reads.
+__device__ int la_prepare_from_T(const SelParams& P, double* buf, int scanrow, const ScanRule& rule,
+                                 double* s_v, int* s_i)
+{
+    const size_t ld = (size_t)P.ld;
+    int qn = -1;
+    if (scanrow >= 0) {
+        MinIdx b; rule_init(rule, b);
+        const double* srow = P.T + (size_t)scanrow * ld;
+        for (int j = threadIdx.x; j < P.C; j += SEL_NT) rule_feed(rule, b, j, srow[j]);
+        b = block_min_idx(b, s_v, s_i);
+        qn = rule_decode(rule, b);
+    }
+    for (int i = threadIdx.x; i < P.R; i += SEL_NT) {
+        if (qn >= 0) buf[i] = P.T[(size_t)i * ld + qn];
+        P.rhsbuf[i] = P.T[(size_t)i * ld + (P.C - 1)];
+    }
+    return qn;
+}
+
+__global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P)
+{
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int iter = st->iter;
+    double* colc = (iter & 1) ? P.col1 : P.col0;
+    ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
+    rule.C = P.C; rule.c0 = 0;
+    int scanrow = P.R - 1;
+    if (rule.forced) {
+        const int k = st->forced_k;
+        scanrow = k < P.fcount ? P.frows[k] : -1;
+        rule.c0 = k < P.fcount ? P.fcols[k] : 0;
+    }
+    int qn = la_prepare_from_T(P, colc, scanrow, rule, s_v, s_i);
+    if (threadIdx.x == 0) st->qn = qn;
+}
+
+__global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
+{
+    extern __shared__ __align__(16) double s_dyn[];
+    __shared__ int s_list[LIST_CAP];
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    __shared__ int s_out;
+
+    DevState* st = P.st;
+    LPX_STAMP_BEGIN
+    if (st->status != LPX_RUNNING) return;
+    LPX_STAMP(0);
+
+    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
+    const int t = threadIdx.x;
+    const int m = P.R - 1;
+    const size_t ld = (size_t)P.ld;
+    double* T = P.T;
+    const int iter = st->iter;
+    const int primal_count = st->primal_count;
+    double* colc = (iter & 1) ? P.col1 : P.col0;     // column q of the current tableau
+    double* coln = (iter & 1) ? P.col0 : P.col1;     // receives column qn of the next one
+    const int q = st->qn;
+    int r = -1, scanrow = -1;
+    int final_status = LPX_RUNNING;
+    ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
+    rule.C = P.C; rule.c0 = 0;
+
+    if (rule.forced) {
+        const int k = st->forced_k;
+        if (k >= P.fcount) {
+            final_status = LPX_OPTIMAL;
+        } else {
+            r = P.frows[k];
+            scanrow = (k + 1 < P.fcount) ? P.frows[k + 1] : -1;
+            rule.c0 = (k + 1 < P.fcount) ? P.fcols[k + 1] : 0;
+            if (t == 0) { P.fchosen[k] = q; st->forced_k = k + 1; }
+            if (q < 0) {                                  // no eligible column: skip this pivot
+                int qn = la_prepare_from_T(P, colc, scanrow, rule, s_v, s_i);
+                if (t == 0) { st->r = -1; st->q = -1; st->qn = qn; }
+                return;
+            }
+        }
+    } else {
+        // primal loop head, Models/PrimalSimplex.cs:95-106
+        if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
+        else if (q < 0) final_status = LPX_OPTIMAL;
+        else {
+            const double eps = P.eps;
+            const double* rb = P.rhsbuf;
+            r = block_hysteresis_argmin(m, P.tol_primal, [&](int i) {
+                    double a = colc[i];
+                    return a > eps ? rb[i] / a : __builtin_inf(); },
+                rbuf, s_list, s_v, s_i, &s_out);
+            if (r < 0) final_status = LPX_UNBOUNDED;
+            scanrow = m;
         }
     }
+    LPX_STAMP(1);
+    if (final_status != LPX_RUNNING) {
+        if (t == 0) { st->status = final_status; st->r = -1; st->q = -1; }
+        return;
+    }
+
+    // Pivot prep (Models/PrimalSimplex.cs:249-250) fused with the lookahead scan of the updated row.
+    const double piv = colc[r];
+    const bool same = (scanrow == r);
+    const double fs = (scanrow >= 0 && !same) ? colc[scanrow] : 0.0;
+    double* trow = T + (size_t)r * ld;
+    const double* srow = T + (size_t)(scanrow >= 0 ? scanrow : 0) * ld;
+    MinIdx best; rule_init(rule, best);
+    for (int j = t; j < P.C; j += SEL_NT) {
+        const double p = trow[j] / piv;
+        trow[j] = p;
+        P.prow[j] = p;
+        if (scanrow >= 0) {
+            const double u = same ? p : srow[j] - fs * p;     // what lpx_update will store at T[s,j]
+            rule_feed(rule, best, j, u);
+        }
+    }
+    LPX_STAMP(2);
+    best = block_min_idx(best, s_v, s_i);                     // barrier inside: prow is complete
+    LPX_STAMP(3);
+    const int qn = (scanrow >= 0) ? rule_decode(rule, best) : -1;
+    if (t == 0) {
+        if (qn >= 0) coln[r] = P.prow[qn];                    // row r is not touched by lpx_update
+        P.rhsbuf[r] = P.prow[P.C - 1];
+        if (!rule.forced) P.basis[r] = q;                     // basis[leaving] = entering, :110
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        st->iter = iter + 1;
+        st->r = r; st->q = q; st->qn = qn;
+        if (!rule.forced) st->primal_count = primal_count + 1;
+    }
+    LPX_STAMP(4);
+    LPX_STAMP_END;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,15 +483,20 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
 static constexpr int UPD_NT = 256;
 static constexpr int UPD_ROWS = 8;
 
-__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int R,
+__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int R, int C,
                                                      const double* __restrict__ prow,
-                                                     const double* __restrict__ pcol,
+                                                     double* fac0, double* fac1,
+                                                     double* __restrict__ rhsbuf,
                                                      const DevState* __restrict__ st,
                                                      int ncw, int nunits)
 {
     if (st->status != LPX_RUNNING) return;
     const int r = st->r;
     if (r < 0) return;
+    const int par = (st->iter - 1) & 1;                   // parity of the pivot being applied
+    const double* __restrict__ fac = par ? fac1 : fac0;   // pivot column snapshot (factors)
+    double* __restrict__ nxt = par ? fac0 : fac1;         // by-product: next pivot's column
+    const int qn = st->qn;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int unit = blockIdx.x * (UPD_NT / 64) + wave;
@@ -334,6 +508,8 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
     const int row0 = rb * UPD_ROWS;
     double* base = T + (size_t)row0 * ld + col;
+    const bool wq = (qn >= 0) && ((qn & ~1) == col);              // this lane owns column qn
+    const bool wr = (rhsbuf != nullptr) && (((C - 1) & ~1) == col);   // this lane owns the RHS column
 
     double2 v[UPD_ROWS];
     double f[UPD_ROWS];
@@ -342,7 +518,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
         const int i = row0 + k;
         if (i < R) {
             v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
-            f[k] = pcol[i];
+            f[k] = fac[i];
         }
     }
 #pragma unroll
@@ -353,6 +529,8 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
             o.x = v[k].x - f[k] * p.x;          // mul, then sub: contraction is off
             o.y = v[k].y - f[k] * p.y;
             *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
+            if (wq) nxt[i] = (qn & 1) ? o.y : o.x;
+            if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
         }
     }
 }
@@ -364,7 +542,11 @@ int select_lds_doubles() { return SEL_LDS_DOUBLES; }
 
 hipError_t kernels_init()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SEL_LDS_DOUBLES * (int)sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select_la),
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                SEL_LDS_DOUBLES * (int)sizeof(double));
 }
@@ -376,14 +558,32 @@ hipError_t launch_select(const SelParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_update(double* T, int ld, int R, const double* prow, const double* pcol,
-                         const DevState* st, hipStream_t s)
+hipError_t launch_select_la(const SelParams& p, hipStream_t s)
+{
+    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
+    hipLaunchKernelGGL(lpx_select_la, dim3(1), dim3(SEL_NT), dyn, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_la_init(const SelParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_la_init, dim3(1), dim3(SEL_NT), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, double* fac0, double* fac1,
+                         double* rhsbuf, const DevState* st, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     const int ncw = (ld + 127) / 128;
     const int nrb = (R + UPD_ROWS - 1) / UPD_ROWS;
     const int nunits = ncw * nrb;
     const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
-    hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s, T, ld, R, prow, pcol, st, ncw, nunits);
+    if (e0 && e1)
+        hipExtLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0,
+                              T, ld, R, C, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+    else
+        hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s,
+                           T, ld, R, C, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
     return hipGetLastError();
 }
 

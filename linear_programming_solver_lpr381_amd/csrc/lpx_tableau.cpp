@@ -52,6 +52,9 @@ struct lpx_tableau {
     double* snapT = nullptr;    // snapshot
     double* prow = nullptr;     // [ld]
     double* pcol = nullptr;     // [R]
+    double* col0 = nullptr;     // [R] lookahead column buffers (ping-pong)
+    double* col1 = nullptr;
+    double* rhsbuf = nullptr;   // [R]
     double* ws = nullptr;       // [max(R,C)]
     int32_t* basis = nullptr;   // [R-1]
     int32_t* snapBasis = nullptr;
@@ -146,6 +149,9 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     ALLOC(t->T, tb);
     ALLOC(t->prow, sizeof(double) * t->ld);
     ALLOC(t->pcol, sizeof(double) * R);
+    ALLOC(t->col0, sizeof(double) * R);
+    ALLOC(t->col1, sizeof(double) * R);
+    ALLOC(t->rhsbuf, sizeof(double) * R);
     ALLOC(t->ws, sizeof(double) * wsn);
     ALLOC(t->basis, sizeof(int32_t) * (R > 1 ? R - 1 : 1));
     ALLOC(t->trace, sizeof(int32_t) * 2 * t->trace_cap);
@@ -160,6 +166,9 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     hipMemsetAsync(t->T, 0, tb, t->stream);
     hipMemsetAsync(t->prow, 0, sizeof(double) * t->ld, t->stream);
     hipMemsetAsync(t->pcol, 0, sizeof(double) * R, t->stream);
+    hipMemsetAsync(t->col0, 0, sizeof(double) * R, t->stream);
+    hipMemsetAsync(t->col1, 0, sizeof(double) * R, t->stream);
+    hipMemsetAsync(t->rhsbuf, 0, sizeof(double) * R, t->stream);
     hipMemsetAsync(t->basis, 0, sizeof(int32_t) * (R > 1 ? R - 1 : 1), t->stream);
     hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream);
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));
@@ -173,7 +182,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     if (t->stream) hipStreamSynchronize(t->stream);
     drop_graph(t);
     for (hipEvent_t e : t->events) hipEventDestroy(e);
-    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->ws);
+    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws);
     hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen);
     if (t->hst) hipHostFree(t->hst);
@@ -249,6 +258,15 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
     return 0;
 }
 
+#ifdef LPX_STAMPS
+int lpx_debug_ws(lpx_tableau* t, unsigned long long* out, int n, int clear)
+{
+    LPX_HIP_TRY(hipMemcpy(out, t->ws, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (clear) LPX_HIP_TRY(hipMemset(t->ws, 0, sizeof(unsigned long long) * n));
+    return 0;
+}
+#endif
+
 int lpx_tableau_trace(lpx_tableau* t, int32_t* trace, int cap, int* n)
 {
     if (!t) return LPX_EINVAL;
@@ -273,10 +291,15 @@ namespace {
 
 bool same_params(const SelParams& a, const SelParams& b) { return std::memcmp(&a, &b, sizeof(SelParams)) == 0; }
 
-int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s)
+int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
-    LPX_HIP_TRY(launch_select(p, s));
-    LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->prow, t->pcol, t->st, s));
+    if (p.mode == MODE_DUAL) {
+        LPX_HIP_TRY(launch_select(p, s));
+        LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->pcol, t->pcol, nullptr, t->st, s, e0, e1));
+    } else {
+        LPX_HIP_TRY(launch_select_la(p, s));
+        LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->col0, t->col1, t->rhsbuf, t->st, s, e0, e1));
+    }
     return 0;
 }
 
@@ -313,6 +336,7 @@ int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budge
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1;
     init.phase = (p.mode == MODE_DUAL) ? 0 : 2;
+    init.qn = -1;
     LPX_HIP_TRY(hipMemcpyAsync(t->st, &init, sizeof(init), hipMemcpyHostToDevice, t->stream));
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));
 
@@ -327,6 +351,10 @@ int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budge
     if (graph) { int rc = build_graph(t, p, batch); if (rc) return rc; }
 
     const double t0 = now_ms();
+    if (p.mode != MODE_DUAL) {           // lookahead path: first entering column + its gather, once
+        LPX_HIP_TRY(launch_la_init(p, t->stream));
+        local.launches += 1;
+    }
     int fired = 0;
     long long enq = 0;
     int status = LPX_RUNNING;
@@ -336,10 +364,8 @@ int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budge
             LPX_HIP_TRY(hipGraphLaunch(t->gexec, t->stream));
         } else if (o->profile) {
             for (int i = 0; i < batch; ++i) {
-                LPX_HIP_TRY(launch_select(p, t->stream));
-                LPX_HIP_TRY(hipEventRecord(t->events[2 * i], t->stream));
-                LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->prow, t->pcol, t->st, t->stream));
-                LPX_HIP_TRY(hipEventRecord(t->events[2 * i + 1], t->stream));
+                int rc = enqueue_pair(t, p, t->stream, t->events[2 * i], t->events[2 * i + 1]);
+                if (rc) return rc;
             }
         } else {
             for (int i = 0; i < batch; ++i) { int rc = enqueue_pair(t, p, t->stream); if (rc) return rc; }
@@ -388,7 +414,7 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
 {
     SelParams p; std::memset(&p, 0, sizeof(p));
     p.T = t->T; p.ld = t->ld; p.R = t->R; p.C = t->C;
-    p.prow = t->prow; p.pcol = t->pcol; p.basis = t->basis; p.trace = t->trace; p.trace_cap = t->trace_cap;
+    p.prow = t->prow; p.pcol = t->pcol; p.col0 = t->col0; p.col1 = t->col1; p.rhsbuf = t->rhsbuf; p.basis = t->basis; p.trace = t->trace; p.trace_cap = t->trace_cap;
     p.st = t->st;
     p.eps = o->eps;
     p.tol_fdf = o->ratio_tol; p.tol_dual = o->ratio_tol;
