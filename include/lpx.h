@@ -126,6 +126,33 @@ int lpx_dual_tableau(double* T, int R, int C, int32_t* basis, double eps, double
                      int fdf_guard, int max_iter, int cleanup,
                      lpx_pivot_cb cb, void* user, lpx_stats* st);
 
+/* ---- revised primal simplex (device-resident) ------------------------------------------------ */
+/* Replaces the loop of RevisedPrimalSimplex.Solve (Models/RevisedPrimalSimplex.cs:58-142):
+ * pricing  r_N = c_N - (c_B B^-1) N  (MultiplyRow :365-378, Subtract :388-393),
+ * entering = first strict minimum below -Eps in Nidx LIST order (:76-83),
+ * direction d = B^-1 a_q (Multiply :325-336), ratio test with 1e-12 hysteresis (:99-112),
+ * basis bookkeeping Bidx[r]=q; Nidx.RemoveAt(pos); Nidx.Add(leaving) (:121-124).
+ * Where the reference re-inverts B from scratch every iteration (Invert :402-456, 4m^3 flop) the
+ * engine applies the mathematically equal rank-1 (product-form) update to the device-resident
+ * (m+1)x(m+1) matrix [[B^-1, x_B], [c_B B^-1, z]] with the same update kernel as the tableau path:
+ * same pivot sequence away from ties, objective within 1e-9 relative (DESIGN.md "Revised path").
+ *
+ * A: m x n row-major structural columns (the slack identity is implicit); c[n]: costs of the
+ * standardised MINIMISATION (c = -C for a Max model, :153-154); b[m] >= -1e-9 (:19-21 is the
+ * caller's precondition check). */
+typedef struct lpx_revised lpx_revised;
+int  lpx_revised_create(int m, int n, const double* A, const double* c, const double* b, lpx_revised** out);
+void lpx_revised_destroy(lpx_revised* r);
+int  lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st);
+/* Bidx[m]; Nidx[n] in the reference's list order; xB[m]; *z = c_B . x_B of the minimised model. */
+int  lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB, double* z);
+int  lpx_revised_binv(lpx_revised* r, double* Binv /* [m*m] row-major */);
+int  lpx_revised_trace(lpx_revised* r, int32_t* trace /* [2*cap]: (leaveRow, entering) */, int cap, int* n);
+/* one-shot on host buffers */
+int  lpx_revised_solve(const double* A, int m, int n, const double* c, const double* b,
+                       int32_t* Bidx, int32_t* Nidx, double* xB, double* z,
+                       double eps, int max_iter, lpx_pivot_cb cb, void* user, lpx_stats* st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,5 +6,6 @@ behind the C ABI of include/lpx.h); this package is the host-side binding and ha
 from . import _lib
 from ._lib import LpxError, default_opts
 from .tableau import DeviceTableau, primal_tableau, dual_tableau
+from .revised import DeviceRevised
 
-__all__ = ["_lib", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau"]
+__all__ = ["_lib", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau", "DeviceRevised"]

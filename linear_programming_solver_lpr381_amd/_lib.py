@@ -86,6 +86,15 @@ def lib() -> C.CDLL:
                                      C.POINTER(Stats)]
     L.lpx_dual_tableau.argtypes = [dp, C.c_int, C.c_int, ip, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_int, PIVOT_CB, vp, C.POINTER(Stats)]
+    L.lpx_revised_create.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.POINTER(vp)]
+    L.lpx_revised_destroy.argtypes = [vp]
+    L.lpx_revised_destroy.restype = None
+    L.lpx_revised_run.argtypes = [vp, C.POINTER(RunOpts), PIVOT_CB, vp, C.POINTER(Stats)]
+    L.lpx_revised_result.argtypes = [vp, ip, ip, dp, dp]
+    L.lpx_revised_binv.argtypes = [vp, dp]
+    L.lpx_revised_trace.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
+    L.lpx_revised_solve.argtypes = [dp, C.c_int, C.c_int, dp, dp, ip, ip, dp, dp, C.c_double, C.c_int,
+                                    PIVOT_CB, vp, C.POINTER(Stats)]
     _lib = L
     return L
 

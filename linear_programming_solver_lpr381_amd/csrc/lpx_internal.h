@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
+#include <functional>
 #include "../../include/lpx.h"
 
 namespace lpx {
@@ -57,6 +59,28 @@ hipError_t kernels_init();          // one-time function attributes
 int select_lds_doubles();           // capacity of the dynamic LDS ratio buffer
 
 void set_error(const std::string& msg);
+int ensure_device();                // binds a device and sets kernel attributes once
+double now_ms();
+
+// Generic device-resident loop: enqueue `batch` iterations (eager, hipGraph replay, or event-
+// bracketed), poll the device state once per batch, fire pivot callbacks from the trace.
+struct LoopCtx {
+    hipStream_t stream = nullptr;
+    DevState* st = nullptr;            // device
+    DevState* hst = nullptr;           // pinned host mirror
+    int32_t* trace = nullptr; int trace_cap = 0;
+    std::vector<hipEvent_t>* events = nullptr;
+    hipGraphExec_t* gexec = nullptr;   // cached graph of *g_batch iterations keyed by *g_key
+    int* g_batch = nullptr;
+    std::string* g_key = nullptr;
+    std::string key;                   // identifies the captured parameter set
+    std::function<int(hipStream_t, hipEvent_t, hipEvent_t)> enqueue_iter;  // one iteration
+    std::function<int(hipStream_t)> prologue;                               // once, before the loop
+    int launches_per_iter = 2;
+    bool profile_maps = true;          // pivot k of a batch == k-th enqueued iteration
+};
+int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
+                    lpx_pivot_cb cb, void* user, lpx_stats* stats);
 
 }  // namespace lpx
 

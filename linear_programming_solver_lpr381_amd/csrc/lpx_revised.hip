@@ -1,0 +1,417 @@
+// lpx_revised.hip -- revised primal simplex on gfx950: pricing / FTRAN as wave-per-vector GEMVs over
+// HBM-resident A^T and B^-1, product-form update through the tableau path's lpx_update kernel.
+//
+// Device data (all FP64, row-major, leading dimensions padded to 16 doubles):
+//   AT [n x ldat]   A transposed: column j of A is a contiguous row -> pricing is a row dot, and
+//                   the entering column needs no strided gather.
+//   W  [(m+1) x ldw] = [[B^-1, x_B], [pi, z]]  with pi = c_B B^-1, z = c_B x_B.  A pivot on row r with
+//                   column vector f = [d; pi.a_q - c_q] (d = B^-1 a_q) is the Gauss-Jordan update of
+//                   Models/PrimalSimplex.cs:245-257 applied to W -> reuses lpx_update unchanged,
+//                   including its contiguous copy of the last column (x_B) for the ratio test.
+//   key[n+m]        order key of nonbasic columns (-1 = basic).  Nidx.RemoveAt + Nidx.Add(leaving)
+//                   (Models/RevisedPrimalSimplex.cs:123-124) preserves relative order, so "first in
+//                   list order" == smallest key with keys handed out increasingly.
+#include "lpx_block.h"
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <utility>
+
+namespace lpx {
+
+struct RvParams {
+    int m, n, ldat, ldw;
+    const double* AT; const double* c;   // c[n] (structural costs; slack costs are 0)
+    double* W; double* prow; double* fac; double* rhsbuf; double* rc; double* aq;
+    int32_t* Bidx; int32_t* key; int32_t* trace; int trace_cap;
+    DevState* st;
+    double eps, tol; int max_iter;
+    double* ws; int rcap;
+};
+
+static constexpr int RV_NT = 1024;
+static constexpr int RV_NW = RV_NT / 64;
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// A (m x n, packed) -> AT (n x ldat): 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void rv_transpose(const double* __restrict__ A, int m, int n,
+                                                    double* __restrict__ AT, int ldat)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;       // bx: column of A, by: row of A
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        int i = by + k, j = bx + tx;
+        tile[k][tx] = (i < m && j < n) ? A[(size_t)i * n + j] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int j = bx + k, i = by + tx;
+        if (j < n && i < m) AT[(size_t)j * ldat + i] = tile[tx][k];
+    }
+}
+
+// rc[j] = c_j - pi . A[:,j]  for nonbasic structural j (+inf for basic ones).  One wave per column.
+// MultiplyRow + Subtract, Models/RevisedPrimalSimplex.cs:71-72.
+__global__ __launch_bounds__(256) void rv_price_dot(RvParams P)
+{
+    if (P.st->status != LPX_RUNNING) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= P.n) return;
+    if (P.key[j] < 0) { if (lane == 0) P.rc[j] = __builtin_inf(); return; }
+    const double* __restrict__ a = P.AT + (size_t)j * P.ldat;
+    const double* __restrict__ pi = P.W + (size_t)P.m * P.ldw;
+    double s0 = 0.0, s1 = 0.0;
+    const int mp = P.m & ~1;
+    for (int k = lane * 2; k < mp; k += 128) {
+        const double2 av = *reinterpret_cast<const double2*>(a + k);
+        const double2 pv = *reinterpret_cast<const double2*>(pi + k);
+        s0 += av.x * pv.x;
+        s1 += av.y * pv.y;
+    }
+    if ((P.m & 1) && lane == 0) s0 += a[P.m - 1] * pi[P.m - 1];
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) P.rc[j] = P.c[j] - s;
+}
+
+struct Cand { double v; int key; int col; };
+__device__ __forceinline__ Cand cand_pick(Cand a, Cand b)
+{
+    if (b.v < a.v || (b.v == a.v && b.key < a.key)) return b;
+    return a;
+}
+
+// entering variable (Models/RevisedPrimalSimplex.cs:76-92) + dense copy of its column + the
+// objective-row factor.  One workgroup.
+__global__ __launch_bounds__(RV_NT) void rv_price_pick(RvParams P)
+{
+    __shared__ double s_v[RV_NW];
+    __shared__ int s_k[RV_NW];
+    __shared__ int s_c[RV_NW];
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (st->iter >= P.max_iter) {                       // :66 / :144
+        if (t == 0) { st->status = LPX_ITER_LIMIT; st->r = -1; }
+        return;
+    }
+    const double* pi = P.W + (size_t)P.m * P.ldw;
+    Cand best; best.v = -P.eps; best.key = INT_MAX; best.col = -1;
+    for (int j = t; j < P.n; j += RV_NT) {
+        const int k = P.key[j];
+        if (k >= 0) { Cand c; c.v = P.rc[j]; c.key = k; c.col = j; if (c.v < -P.eps) best = cand_pick(best, c); }
+    }
+    for (int s = t; s < P.m; s += RV_NT) {
+        const int k = P.key[P.n + s];
+        if (k >= 0) { Cand c; c.v = 0.0 - pi[s]; c.key = k; c.col = P.n + s; if (c.v < -P.eps) best = cand_pick(best, c); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Cand o; o.v = __shfl_xor(best.v, d, 64); o.key = __shfl_xor(best.key, d, 64); o.col = __shfl_xor(best.col, d, 64);
+        best = cand_pick(best, o);
+    }
+    if (lane == 0) { s_v[wave] = best.v; s_k[wave] = best.key; s_c[wave] = best.col; }
+    __syncthreads();
+    Cand w; w.v = s_v[lane & (RV_NW - 1)]; w.key = s_k[lane & (RV_NW - 1)]; w.col = s_c[lane & (RV_NW - 1)];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Cand o; o.v = __shfl_xor(w.v, d, 64); o.key = __shfl_xor(w.key, d, 64); o.col = __shfl_xor(w.col, d, 64);
+        w = cand_pick(w, o);
+    }
+    const int q = w.col;
+    if (q < 0) {                                        // :84-90
+        if (t == 0) { st->status = LPX_OPTIMAL; st->r = -1; st->q = -1; }
+        return;
+    }
+    for (int k = t; k < P.m; k += RV_NT)
+        P.aq[k] = (q < P.n) ? P.AT[(size_t)q * P.ldat + k] : ((k == q - P.n) ? 1.0 : 0.0);
+    if (t == 0) { st->q = q; P.fac[P.m] = -w.v; }       // pi.a_q - c_q = -(reduced cost)
+}
+
+// d = B^-1 a_q (Multiply, Models/RevisedPrimalSimplex.cs:96).  One wave per row of W.
+__global__ __launch_bounds__(256) void rv_ftran(RvParams P)
+{
+    if (P.st->status != LPX_RUNNING) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.m) return;
+    const double* __restrict__ w = P.W + (size_t)i * P.ldw;
+    const double* __restrict__ a = P.aq;
+    double s0 = 0.0, s1 = 0.0;
+    const int mp = P.m & ~1;
+    for (int k = lane * 2; k < mp; k += 128) {
+        const double2 wv = *reinterpret_cast<const double2*>(w + k);
+        const double2 av = *reinterpret_cast<const double2*>(a + k);
+        s0 += wv.x * av.x;
+        s1 += wv.y * av.y;
+    }
+    if ((P.m & 1) && lane == 0) s0 += w[P.m - 1] * a[P.m - 1];
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) P.fac[i] = s;
+}
+
+// Ratio test (Models/RevisedPrimalSimplex.cs:99-112, hysteresis 1e-12), normalisation of the pivot row
+// of W, and the basis bookkeeping of :121-124.  One workgroup.
+__global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
+{
+    extern __shared__ __align__(16) double s_dyn[];
+    __shared__ int s_list[LIST_CAP];
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    __shared__ int s_out;
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
+    const int t = threadIdx.x;
+    const int m = P.m;
+    const int iter = st->iter;
+    const int q = st->q;
+    const double eps = P.eps;
+    const double* d = P.fac;
+    const double* xb = P.rhsbuf;
+    const int r = block_hysteresis_argmin(m, P.tol, [&](int i) {
+            double di = d[i];
+            return di > eps ? xb[i] / di : __builtin_inf(); },
+        rbuf, s_list, s_v, s_i, &s_out);
+    if (r < 0) {                                                    // :113-118
+        if (t == 0) { st->status = LPX_UNBOUNDED; st->r = -1; }
+        return;
+    }
+    const double piv = d[r];
+    double* wrow = P.W + (size_t)r * P.ldw;
+    const int C = m + 1;
+    for (int j = t; j < C; j += SEL_NT) {
+        const double p = wrow[j] / piv;
+        wrow[j] = p;
+        P.prow[j] = p;
+    }
+    __syncthreads();
+    if (t == 0) {
+        P.rhsbuf[r] = P.prow[m];
+        const int leaving = P.Bidx[r];                              // :121-124
+        P.Bidx[r] = q;
+        P.key[q] = -1;
+        P.key[leaving] = st->pad[0];
+        st->pad[0] = st->pad[0] + 1;
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        st->iter = iter + 1;
+        st->r = r; st->qn = -1;
+    }
+}
+
+hipError_t rv_kernels_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(rv_select),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SEL_LDS_DOUBLES * (int)sizeof(double));
+}
+
+}  // namespace lpx
+
+// ---------------------------------------------------------------------------------------------------
+// host side: handle + C ABI
+// ---------------------------------------------------------------------------------------------------
+using namespace lpx;
+
+struct lpx_revised {
+    int m = 0, n = 0, ldat = 0, ldw = 0;
+    double *AT = nullptr, *c = nullptr, *W = nullptr, *prow = nullptr, *fac = nullptr, *rhsbuf = nullptr,
+           *rc = nullptr, *aq = nullptr, *ws = nullptr;
+    int32_t *Bidx = nullptr, *key = nullptr, *trace = nullptr;
+    int trace_cap = 1 << 16;
+    DevState* st = nullptr; DevState* hst = nullptr;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t gexec = nullptr; int g_batch = 0; std::string g_key;
+    std::vector<hipEvent_t> events;
+};
+
+static RvParams rv_params(lpx_revised* r, const lpx_run_opts* o)
+{
+    RvParams p; std::memset(&p, 0, sizeof(p));
+    p.m = r->m; p.n = r->n; p.ldat = r->ldat; p.ldw = r->ldw;
+    p.AT = r->AT; p.c = r->c; p.W = r->W; p.prow = r->prow; p.fac = r->fac; p.rhsbuf = r->rhsbuf;
+    p.rc = r->rc; p.aq = r->aq; p.Bidx = r->Bidx; p.key = r->key; p.trace = r->trace; p.trace_cap = r->trace_cap;
+    p.st = r->st; p.eps = o->eps; p.tol = o->ratio_tol; p.max_iter = o->max_iter;
+    p.ws = r->ws; p.rcap = (r->m + 1 <= select_lds_doubles()) ? r->m + 1 : 0;
+    return p;
+}
+
+static int rv_enqueue(lpx_revised* r, const RvParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    hipLaunchKernelGGL(rv_price_dot, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(rv_price_pick, dim3(1), dim3(RV_NT), 0, s, p);
+    hipLaunchKernelGGL(rv_ftran, dim3((p.m + 3) / 4), dim3(256), 0, s, p);
+    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
+    hipLaunchKernelGGL(rv_select, dim3(1), dim3(SEL_NT), dyn, s, p);
+    LPX_HIP_TRY(hipGetLastError());
+    LPX_HIP_TRY(launch_update(p.W, p.ldw, p.m + 1, p.m + 1, p.prow, p.fac, p.fac, p.rhsbuf, p.st, s, e0, e1));
+    return 0;
+}
+
+extern "C" {
+
+void lpx_revised_destroy(lpx_revised* r)
+{
+    if (!r) return;
+    if (r->stream) hipStreamSynchronize(r->stream);
+    if (r->gexec) hipGraphExecDestroy(r->gexec);
+    for (hipEvent_t e : r->events) hipEventDestroy(e);
+    hipFree(r->AT); hipFree(r->c); hipFree(r->W); hipFree(r->prow); hipFree(r->fac); hipFree(r->rhsbuf);
+    hipFree(r->rc); hipFree(r->aq); hipFree(r->ws); hipFree(r->Bidx); hipFree(r->key); hipFree(r->trace);
+    hipFree(r->st);
+    if (r->hst) hipHostFree(r->hst);
+    if (r->stream) hipStreamDestroy(r->stream);
+    delete r;
+}
+
+int lpx_revised_create(int m, int n, const double* A, const double* c, const double* b, lpx_revised** out)
+{
+    if (!out || m < 1 || n < 1 || !A || !c || !b) { set_error("lpx_revised_create: bad argument"); return LPX_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    static std::once_flag once; static hipError_t ierr = hipSuccess;
+    std::call_once(once, [] { ierr = rv_kernels_init(); });
+    if (ierr != hipSuccess) { set_error("rv_select attribute setup failed"); return LPX_EDEVICE; }
+    lpx_revised* r = new lpx_revised();
+    r->m = m; r->n = n;
+    r->ldat = (m + 15) / 16 * 16;
+    r->ldw = (m + 1 + 15) / 16 * 16;
+    const size_t atb = sizeof(double) * (size_t)n * r->ldat;
+    const size_t wb = sizeof(double) * (size_t)(m + 1) * r->ldw;
+    double* Atmp = nullptr;
+#define RALLOC(ptr, bytes)                                                              \
+    do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                            \
+         if (e_ != hipSuccess) { set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_)); \
+             hipFree(Atmp); lpx_revised_destroy(r); return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE; } } while (0)
+    RALLOC(r->AT, atb); RALLOC(r->c, sizeof(double) * n); RALLOC(r->W, wb);
+    RALLOC(r->prow, sizeof(double) * r->ldw); RALLOC(r->fac, sizeof(double) * (m + 1));
+    RALLOC(r->rhsbuf, sizeof(double) * (m + 1)); RALLOC(r->rc, sizeof(double) * n);
+    RALLOC(r->aq, sizeof(double) * r->ldat); RALLOC(r->ws, sizeof(double) * (m + 1));
+    RALLOC(r->Bidx, sizeof(int32_t) * m); RALLOC(r->key, sizeof(int32_t) * (n + m));
+    RALLOC(r->trace, sizeof(int32_t) * 2 * r->trace_cap); RALLOC(r->st, sizeof(DevState));
+    RALLOC(Atmp, sizeof(double) * (size_t)m * n);
+#undef RALLOC
+    if (hipHostMalloc((void**)&r->hst, sizeof(DevState)) != hipSuccess ||
+        hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("pinned state / stream creation failed"); hipFree(Atmp); lpx_revised_destroy(r); return LPX_EDEVICE;
+    }
+    hipStream_t s = r->stream;
+    hipMemsetAsync(r->st, 0, sizeof(DevState), s);
+    hipMemsetAsync(r->AT, 0, atb, s);
+    hipMemsetAsync(r->W, 0, wb, s);
+    hipMemsetAsync(r->prow, 0, sizeof(double) * r->ldw, s);
+    hipMemsetAsync(r->aq, 0, sizeof(double) * r->ldat, s);
+    hipMemsetAsync(r->fac, 0, sizeof(double) * (m + 1), s);
+    hipMemsetAsync(r->rhsbuf, 0, sizeof(double) * (m + 1), s);
+    hipMemcpyAsync(Atmp, A, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(r->c, c, sizeof(double) * n, hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(rv_transpose, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, s, Atmp, m, n, r->AT, r->ldat);
+    // W = [[I, b], [0, 0]]  (Invert of the slack basis is exactly I, :58; xB = b, :59; pi = 0, z = 0)
+    std::vector<double> one(m, 1.0);
+    hipMemcpy2DAsync(r->W, sizeof(double) * (r->ldw + 1), one.data(), sizeof(double), sizeof(double), m, hipMemcpyHostToDevice, s);
+    hipMemcpy2DAsync(r->W + m, sizeof(double) * r->ldw, b, sizeof(double), sizeof(double), m, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(r->rhsbuf, b, sizeof(double) * m, hipMemcpyHostToDevice, s);
+    std::vector<int32_t> bidx(m), key(n + m);
+    for (int i = 0; i < m; ++i) bidx[i] = n + i;                 // :47
+    for (int j = 0; j < n; ++j) key[j] = j;                       // :48
+    for (int i = 0; i < m; ++i) key[n + i] = -1;
+    hipMemcpyAsync(r->Bidx, bidx.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(r->key, key.data(), sizeof(int32_t) * (n + m), hipMemcpyHostToDevice, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(Atmp);
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) {
+        set_error(std::string("lpx_revised_create: upload failed: ") + hipGetErrorString(e));
+        lpx_revised_destroy(r); return LPX_EDEVICE;
+    }
+    *out = r;
+    return 0;
+}
+
+int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    if (!r) { set_error("lpx_revised_run: null handle"); return LPX_EINVAL; }
+    lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
+    RvParams p = rv_params(r, o);
+    LoopCtx c;
+    c.stream = r->stream; c.st = r->st; c.hst = r->hst; c.trace = r->trace; c.trace_cap = r->trace_cap;
+    c.events = &r->events; c.gexec = &r->gexec; c.g_batch = &r->g_batch; c.g_key = &r->g_key;
+    c.key.assign(reinterpret_cast<const char*>(&p), sizeof(p));
+    c.enqueue_iter = [r, p](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { return rv_enqueue(r, p, s, e0, e1); };
+    c.launches_per_iter = 5;
+    c.profile_maps = true;
+    DevState init; std::memset(&init, 0, sizeof(init));
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
+    // continue from the handle's current basis: the order-key counter lives in pad[0]
+    LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
+    init.pad[0] = r->hst->pad[0] > 0 ? r->hst->pad[0] : r->n;
+    return run_device_loop(c, init, o, (long long)o->max_iter + 2, cb, user, st);
+}
+
+int lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB, double* z)
+{
+    if (!r) return LPX_EINVAL;
+    const int m = r->m, n = r->n;
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    if (Bidx) LPX_HIP_TRY(hipMemcpy(Bidx, r->Bidx, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    if (xB) LPX_HIP_TRY(hipMemcpy2D(xB, sizeof(double), r->W + m, sizeof(double) * r->ldw, sizeof(double), m, hipMemcpyDeviceToHost));
+    if (z) LPX_HIP_TRY(hipMemcpy(z, r->W + (size_t)m * r->ldw + m, sizeof(double), hipMemcpyDeviceToHost));
+    if (Nidx) {
+        std::vector<int32_t> key(n + m);
+        LPX_HIP_TRY(hipMemcpy(key.data(), r->key, sizeof(int32_t) * (n + m), hipMemcpyDeviceToHost));
+        std::vector<std::pair<int32_t, int32_t>> nb;
+        for (int j = 0; j < n + m; ++j) if (key[j] >= 0) nb.emplace_back(key[j], j);
+        std::sort(nb.begin(), nb.end());
+        for (int j = 0; j < n && j < (int)nb.size(); ++j) Nidx[j] = nb[j].second;
+    }
+    return 0;
+}
+
+int lpx_revised_binv(lpx_revised* r, double* Binv)
+{
+    if (!r || !Binv) return LPX_EINVAL;
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    LPX_HIP_TRY(hipMemcpy2D(Binv, sizeof(double) * r->m, r->W, sizeof(double) * r->ldw, sizeof(double) * r->m, r->m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lpx_revised_trace(lpx_revised* r, int32_t* trace, int cap, int* n)
+{
+    if (!r) return LPX_EINVAL;
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
+    int k = r->hst->iter; if (k > r->trace_cap) k = r->trace_cap;
+    if (n) *n = k;
+    if (trace && cap > 0) { int c = k < cap ? k : cap; if (c > 0) LPX_HIP_TRY(hipMemcpy(trace, r->trace, sizeof(int32_t) * 2 * c, hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
+int lpx_revised_solve(const double* A, int m, int n, const double* c, const double* b,
+                      int32_t* Bidx, int32_t* Nidx, double* xB, double* z,
+                      double eps, int max_iter, lpx_pivot_cb cb, void* user, lpx_stats* st)
+{
+    lpx_revised* r = nullptr;
+    double t0 = now_ms();
+    int rc = lpx_revised_create(m, n, A, c, b, &r);
+    if (rc) return rc;
+    double h2d = now_ms() - t0;
+    lpx_run_opts o; lpx_default_opts(&o, 1); o.eps = eps; o.max_iter = max_iter;
+    lpx_stats local; std::memset(&local, 0, sizeof(local));
+    int status = lpx_revised_run(r, &o, cb, user, &local);
+    if (status >= 0) {
+        t0 = now_ms();
+        rc = lpx_revised_result(r, Bidx, Nidx, xB, z);
+        local.d2h_ms = now_ms() - t0; local.h2d_ms = h2d;
+        if (st) *st = local;
+    }
+    lpx_revised_destroy(r);
+    return (status >= 0 && rc) ? rc : status;
+}
+
+}  // extern "C"

@@ -2,47 +2,10 @@
 // (C ABI of include/lpx.h).  Host code only: kernels live in lpx_kernels.hip.
 #include "lpx_internal.h"
 
-#include <chrono>
 #include <cstring>
-#include <mutex>
 #include <vector>
 
-namespace lpx {
-
-static thread_local std::string g_err;
-void set_error(const std::string& msg) { g_err = msg; }
-
-static std::once_flag g_init_once;
-static hipError_t g_init_err = hipSuccess;
-static int g_device = -1;
-
-static int ensure_device()
-{
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        set_error("no HIP device visible (liblpx has no CPU fallback)");
-        return LPX_EDEVICE;
-    }
-    if (g_device < 0) {
-        g_device = 0;
-        LPX_HIP_TRY(hipSetDevice(0));
-    }
-    std::call_once(g_init_once, [] { g_init_err = kernels_init(); });
-    if (g_init_err != hipSuccess) {
-        set_error(std::string("kernel attribute setup failed: ") + hipGetErrorString(g_init_err));
-        return LPX_EDEVICE;
-    }
-    return 0;
-}
-
-static double now_ms()
-{
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-}  // namespace lpx
+namespace lpx { const std::string& get_error(); extern int g_device; }
 
 using namespace lpx;
 
@@ -67,7 +30,7 @@ struct lpx_tableau {
     // cached graph of `g_batch` (select, update) pairs
     hipGraphExec_t gexec = nullptr;
     int g_batch = 0;
-    SelParams g_params{};
+    std::string g_key;
     std::vector<hipEvent_t> events;
 };
 
@@ -98,10 +61,11 @@ int lpx_init(int device)
 
 int lpx_last_error(char* buf, int len)
 {
-    if (!buf || len <= 0) return (int)g_err.size();
-    std::strncpy(buf, g_err.c_str(), len - 1);
+    const std::string& e = get_error();
+    if (!buf || len <= 0) return (int)e.size();
+    std::strncpy(buf, e.c_str(), len - 1);
     buf[len - 1] = 0;
-    return (int)g_err.size();
+    return (int)e.size();
 }
 
 int lpx_device_name(char* buf, int len)
@@ -285,11 +249,9 @@ int lpx_tableau_trace(lpx_tableau* t, int32_t* trace, int cap, int* n)
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------
-// the loop driver
+// tableau loops on top of the generic driver (lpx_loop.cpp)
 // ---------------------------------------------------------------------------------------------------
 namespace {
-
-bool same_params(const SelParams& a, const SelParams& b) { return std::memcmp(&a, &b, sizeof(SelParams)) == 0; }
 
 int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
@@ -303,111 +265,22 @@ int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e
     return 0;
 }
 
-int build_graph(lpx_tableau* t, const SelParams& p, int batch)
-{
-    if (t->gexec && t->g_batch == batch && same_params(t->g_params, p)) return 0;
-    drop_graph(t);
-    hipGraph_t graph = nullptr;
-    LPX_HIP_TRY(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < batch; ++i) {
-        int rc = enqueue_pair(t, p, t->stream);
-        if (rc) { hipStreamEndCapture(t->stream, &graph); if (graph) hipGraphDestroy(graph); return rc; }
-    }
-    LPX_HIP_TRY(hipStreamEndCapture(t->stream, &graph));
-    hipError_t e = hipGraphInstantiate(&t->gexec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (e != hipSuccess) { t->gexec = nullptr; set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return LPX_EDEVICE; }
-    t->g_batch = batch;
-    t->g_params = p;
-    return 0;
-}
-
-// Runs select/update pairs until the device state leaves LPX_RUNNING.  `budget` bounds the number
-// of pairs ever enqueued (each pair either pivots, changes phase, or terminates).
 int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budget,
              lpx_pivot_cb cb, void* user, lpx_stats* stats)
 {
-    int batch = o->batch > 0 ? o->batch : 64;
-    if (o->profile && batch > 256) batch = 256;
-    const bool graph = o->use_graph && !o->profile;
-    lpx_stats local; std::memset(&local, 0, sizeof(local));
-
-    // reset loop state (tableau and basis stay)
+    LoopCtx c;
+    c.stream = t->stream; c.st = t->st; c.hst = t->hst; c.trace = t->trace; c.trace_cap = t->trace_cap;
+    c.events = &t->events; c.gexec = &t->gexec; c.g_batch = &t->g_batch; c.g_key = &t->g_key;
+    c.key.assign(reinterpret_cast<const char*>(&p), sizeof(p));
+    c.enqueue_iter = [t, p](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { return enqueue_pair(t, p, s, e0, e1); };
+    if (p.mode != MODE_DUAL)           // lookahead path: first entering column + its gather, once
+        c.prologue = [p](hipStream_t s) -> int { LPX_HIP_TRY(launch_la_init(p, s)); return 0; };
+    c.launches_per_iter = 2;
+    c.profile_maps = (p.mode != MODE_DUAL);     // phase hops make the mapping ambiguous in dual mode
     DevState init; std::memset(&init, 0, sizeof(init));
-    init.status = LPX_RUNNING; init.r = -1; init.q = -1;
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1;
     init.phase = (p.mode == MODE_DUAL) ? 0 : 2;
-    init.qn = -1;
-    LPX_HIP_TRY(hipMemcpyAsync(t->st, &init, sizeof(init), hipMemcpyHostToDevice, t->stream));
-    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
-
-    if (o->profile && (int)t->events.size() < 2 * batch) {
-        size_t need = 2 * (size_t)batch;
-        while (t->events.size() < need) {
-            hipEvent_t e;
-            LPX_HIP_TRY(hipEventCreate(&e));
-            t->events.push_back(e);
-        }
-    }
-    if (graph) { int rc = build_graph(t, p, batch); if (rc) return rc; }
-
-    const double t0 = now_ms();
-    if (p.mode != MODE_DUAL) {           // lookahead path: first entering column + its gather, once
-        LPX_HIP_TRY(launch_la_init(p, t->stream));
-        local.launches += 1;
-    }
-    int fired = 0;
-    long long enq = 0;
-    int status = LPX_RUNNING;
-    while (status == LPX_RUNNING && enq < budget) {
-        const int iter_before = fired;
-        if (graph) {
-            LPX_HIP_TRY(hipGraphLaunch(t->gexec, t->stream));
-        } else if (o->profile) {
-            for (int i = 0; i < batch; ++i) {
-                int rc = enqueue_pair(t, p, t->stream, t->events[2 * i], t->events[2 * i + 1]);
-                if (rc) return rc;
-            }
-        } else {
-            for (int i = 0; i < batch; ++i) { int rc = enqueue_pair(t, p, t->stream); if (rc) return rc; }
-        }
-        enq += batch;
-        local.launches += 2 * (long long)batch;
-        LPX_HIP_TRY(hipMemcpyAsync(t->hst, t->st, sizeof(DevState), hipMemcpyDeviceToHost, t->stream));
-        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
-        status = t->hst->status;
-        const int done = t->hst->iter;
-        if (o->profile) {
-            // every pair of this batch that completed a pivot ran a full update; in primal/forced
-            // mode those are exactly the first (done - iter_before) pairs of the batch.
-            int full = done - iter_before;
-            if (p.mode == MODE_DUAL) full = 0;       // phase hops make the mapping ambiguous: not profiled
-            for (int i = 0; i < full && i < batch; ++i) {
-                float ms = 0.f;
-                LPX_HIP_TRY(hipEventElapsedTime(&ms, t->events[2 * i], t->events[2 * i + 1]));
-                local.update_ms_sum += ms;
-                local.update_launches++;
-            }
-        }
-        if (cb && done > fired) {
-            std::vector<int32_t> tr(2 * (size_t)(done - fired));
-            int lo = fired, hi = done < t->trace_cap ? done : t->trace_cap;
-            if (hi > lo) {
-                LPX_HIP_TRY(hipMemcpy(tr.data(), t->trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
-                for (int k = lo; k < hi; ++k) cb(user, k + 1, tr[2 * (k - lo)], tr[2 * (k - lo) + 1]);
-            }
-        }
-        fired = done;
-    }
-    local.loop_ms = now_ms() - t0;
-    local.pivots = t->hst->iter;
-    local.fdf_pivots = t->hst->fdf_count;
-    local.cleanup_pivots = (p.mode == MODE_DUAL) ? t->hst->primal_count : 0;
-    if (stats) {
-        double h2d = stats->h2d_ms, d2h = stats->d2h_ms;
-        *stats = local; stats->h2d_ms = h2d; stats->d2h_ms = d2h;
-    }
-    if (status == LPX_RUNNING) { set_error("loop budget exhausted while still running"); return LPX_ITER_LIMIT; }
-    return status;
+    return run_device_loop(c, init, o, budget, cb, user, stats);
 }
 
 SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)

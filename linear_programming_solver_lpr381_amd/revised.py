@@ -1,0 +1,72 @@
+"""Device-resident revised primal simplex: Python face of the lpx_revised_* C ABI (include/lpx.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import RunOpts, Stats, check, default_opts, dp, ip, lib
+from .tableau import PivotCallback, _wrap_cb
+
+
+class DeviceRevised:
+    """[[B^-1, x_B], [c_B B^-1, z]] and A^T resident in HBM (Models/RevisedPrimalSimplex.cs:28-61).
+
+    `A` is the m x n block of structural columns, `c` the costs of the standardised minimisation
+    (c = -C for a Max model, :153-154), `b` the right-hand sides (>= 0).
+    """
+
+    def __init__(self, A: np.ndarray, c: np.ndarray, b: np.ndarray):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        assert c.shape == (n,) and b.shape == (m,)
+        self.m, self.n = m, n
+        self._h = C.c_void_p()
+        check(lib().lpx_revised_create(m, n, A.ctypes.data_as(dp), c.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                                       C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().lpx_revised_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def run(self, opts: Optional[RunOpts] = None, cb: Optional[PivotCallback] = None, **kw) -> Tuple[int, dict]:
+        o = opts if opts is not None else default_opts(True, **kw)
+        st = Stats()
+        c = _wrap_cb(cb)
+        rc = check(lib().lpx_revised_run(self._h, C.byref(o), c, None, C.byref(st)))
+        return rc, st.as_dict()
+
+    def result(self):
+        """Returns (Bidx[m], Nidx[n] in list order, xB[m], z = c_B . x_B)."""
+        Bidx = np.zeros(self.m, np.int32)
+        Nidx = np.zeros(self.n, np.int32)
+        xB = np.zeros(self.m, np.float64)
+        z = C.c_double()
+        check(lib().lpx_revised_result(self._h, Bidx.ctypes.data_as(ip), Nidx.ctypes.data_as(ip),
+                                       xB.ctypes.data_as(dp), C.byref(z)))
+        return Bidx, Nidx, xB, z.value
+
+    def binv(self) -> np.ndarray:
+        B = np.zeros((self.m, self.m), np.float64)
+        check(lib().lpx_revised_binv(self._h, B.ctypes.data_as(dp)))
+        return B
+
+    def trace(self) -> np.ndarray:
+        n = C.c_int()
+        check(lib().lpx_revised_trace(self._h, None, 0, C.byref(n)))
+        tr = np.zeros((max(n.value, 1), 2), np.int32)
+        check(lib().lpx_revised_trace(self._h, tr.ctypes.data_as(ip), n.value, C.byref(n)))
+        return tr[: n.value].copy()
