@@ -116,6 +116,16 @@ int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
 int lpx_forced_pivots_run(lpx_tableau* t, const int32_t* rows, const int32_t* cols, int count,
                           double thresh, int32_t* chosen, const lpx_run_opts* o, lpx_stats* st);
 
+/* x[basis[i]] = T[i,last] for basis[i] < nvars, *z = T[m,last] (FinalizeReport,
+ * Models/PrimalSimplex.cs:130-138) without downloading the tableau. */
+int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z);
+
+/* Branch-and-bound node batches: runs `count` independent tableaux to completion,
+ * interleaving their batches on their own streams so that small node LPs overlap on one GPU.
+ * dual[i] selects lpx_dual_run (1) or lpx_primal_run (0) semantics; statuses[i] gets each status. */
+int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
+                  const lpx_run_opts* dual_opts, int* statuses, lpx_stats* stats /* [count] or NULL */);
+
 /* ---- one-shot entry points on host buffers (what the C# shim binds) -------------------------- */
 /* Replaces the loop of PrimalSimplex.Solve (Models/PrimalSimplex.cs:92-124) on the `double[,]`
  * built by BuildTableau (:179-203).  T and basis are updated in place. */
@@ -152,6 +162,84 @@ int  lpx_revised_trace(lpx_revised* r, int32_t* trace /* [2*cap]: (leaveRow, ent
 int  lpx_revised_solve(const double* A, int m, int n, const double* c, const double* b,
                        int32_t* Bidx, int32_t* Nidx, double* xB, double* z,
                        double eps, int max_iter, lpx_pivot_cb cb, void* user, lpx_stats* st);
+
+/* ---- 0/1 knapsack branch and bound: batched bounds ------------------------------------------- */
+/* Items are kept in HBM in the reference's ratio order (Models/BranchAndBoundKnapsack.cs:75-79).
+ * lpx_knapsack_relax_batch evaluates ComputeRelaxation (:431-491) for `count` nodes in one launch, one
+ * workgroup per node.  Node k is the list of its fixed decisions fix_idx[off[k]..off[k+1]) (ORIGINAL
+ * item indices, ascending) with values fix_val (0/1) -- the reference's int[n] Assigned (:25) without
+ * the undecided entries.  Outputs per node: profit (= bound), weight, the fractional item's position in
+ * ratio order (-1 if none) and its fraction. */
+typedef struct lpx_knapsack lpx_knapsack;
+int  lpx_knapsack_create(const double* profit, const double* weight, int n, double cap, lpx_knapsack** out);
+void lpx_knapsack_destroy(lpx_knapsack* k);
+int  lpx_knapsack_order(lpx_knapsack* k, int32_t* order /* [n]: ratio rank -> original index */);
+int  lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
+                              const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                              double* frac_val);
+
+/* ---- model level: the reference's plugin boundary through a C ABI ------------------------------ */
+/* `ILPAlgorithm.Solve(LPProblem, Action<string,bool[,]>) -> SimplexResult` (Models/IPLAlgorithm.cs:5-8)
+ * as dispatched by `LPSolver.Solve(problem, algorithmName, cb)` (Models/LPSolver.cs:16-59).  The host
+ * side (model preparation, tableau construction, report text, B&B tree) is the C++ mirror in
+ * csrc/host/; the loops run on the GPU.  Used by tools/lpx_cli and the Python binding. */
+enum { LPX_MAX = 0, LPX_MIN = 1 };                 /* Sense, Models/PrimalSimplex.cs:8 */
+enum { LPX_LE = 0, LPX_GE = 1, LPX_EQ = 2 };       /* Rel,   Models/PrimalSimplex.cs:9 */
+
+typedef struct lpx_problem {                       /* LPProblem, Models/PrimalSimplex.cs:20-36 */
+    int sense, n, m;
+    const double* c;      /* [n]   C */
+    const double* A;      /* [m*n] Constraints[i].A, row-major */
+    const int32_t* rel;   /* [m]   Constraints[i].Relation */
+    const double* b;      /* [m]   Constraints[i].B */
+} lpx_problem;
+
+typedef struct lpx_solve_opts {
+    int max_iter;          /* 0 = 10000 */
+    int batch;             /* 0 = default */
+    int render_iterations; /* 1 = text callback receives the whole formatted tableau per pivot */
+    int dual_flags;        /* 0 = faithful DualSimplex (defects D1/D2), 7 = repaired */
+    int bnb_mode;          /* 0 = faithful, 1 = repaired */
+    int bnb_search;        /* 0 = reference DFS, 1 = level-synchronous sharded frontier */
+    int concurrent_nodes;  /* node LPs in flight per GPU (level search) */
+    int rank, world;       /* shard of this process (level search / knapsack rounds) */
+    int64_t max_nodes;     /* 0 = unlimited */
+    /* incumbent exchange, MAX over ranks in place (RCCL all-reduce in production); NULL = 1 process */
+    void (*allreduce_max)(void* user, double* vals, int count);
+    void* allreduce_user;
+    /* Action<string,bool[,]>: text + optional R x C highlight mask (NULL = none) */
+    void (*text_cb)(void* user, const char* text, const uint8_t* highlight, int R, int C);
+    void* text_user;
+} lpx_solve_opts;
+
+typedef struct lpx_result {                        /* SimplexResult, Models/PrimalSimplex.cs:38-49 */
+    int status;            /* LPX_OPTIMAL / LPX_UNBOUNDED / LPX_INFEASIBLE */
+    int has_solution;      /* 0 == Solution/Tableau/Basis/VarNames are null in the reference (defect D2, revised) */
+    double optimal_value;  /* OptimalValue */
+    int n; double* x;      /* Solution [n] */
+    int R, C; double* T;   /* Tableau [R*C] */
+    int32_t* basis;        /* Basis [R-1] */
+    int n_pivots; int32_t* trace;   /* (row, col) per pivot */
+    char* report; char* summary;    /* Report, Summary */
+    int64_t lp_solves, nodes;       /* branch and bound */
+    int n_log; int32_t* node_log;   /* [3*n_log]: depth, outcome, branching variable */
+    double* node_z;                 /* [n_log] */
+    double aux[4];                  /* revised: {z_original, z_internal}; knapsack: {relaxations, popped, expanded, max_heap} */
+    lpx_stats stats;
+} lpx_result;
+
+void lpx_default_solve_opts(lpx_solve_opts* o);
+/* Returns 0 and fills *out, or the negative LPX_E_* code of the exception the reference would throw
+ * (message via lpx_last_error). LPX_ITER_LIMIT (3) is returned for its iteration-limit exceptions. */
+int  lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts* o, lpx_result* out);
+void lpx_result_free(lpx_result* r);
+
+typedef struct lpx_parsed { int sense, n, m; double* c; double* A; int32_t* rel; double* b; int ragged; } lpx_parsed;
+/* LPParser.ParseFromText, Models/LPParser.cs:9-79 */
+int  lpx_parse_text(const char* text, lpx_parsed* out);
+void lpx_parsed_free(lpx_parsed* p);
+/* ToString("0.###") as the reference renders tableau cells (Models/PrimalSimplex.cs:280) */
+int  lpx_format_number(double v, char* buf, int len);
 
 #ifdef __cplusplus
 }

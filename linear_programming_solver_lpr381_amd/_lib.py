@@ -41,6 +41,35 @@ class RunOpts(C.Structure):
                 ("use_graph", C.c_int), ("profile", C.c_int)]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int)
+
+
+class Problem(C.Structure):
+    _fields_ = [("sense", C.c_int), ("n", C.c_int), ("m", C.c_int), ("c", dp), ("A", dp), ("rel", ip), ("b", dp)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("batch", C.c_int), ("render_iterations", C.c_int),
+                ("dual_flags", C.c_int), ("bnb_mode", C.c_int), ("bnb_search", C.c_int),
+                ("concurrent_nodes", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("max_nodes", C.c_int64), ("allreduce_max", ALLREDUCE_CB), ("allreduce_user", C.c_void_p),
+                ("text_cb", TEXT_CB), ("text_user", C.c_void_p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("has_solution", C.c_int), ("optimal_value", C.c_double),
+                ("n", C.c_int), ("x", dp), ("R", C.c_int), ("C", C.c_int), ("T", dp), ("basis", ip),
+                ("n_pivots", C.c_int), ("trace", ip), ("report", C.c_char_p), ("summary", C.c_char_p),
+                ("lp_solves", C.c_int64), ("nodes", C.c_int64), ("n_log", C.c_int), ("node_log", ip),
+                ("node_z", dp), ("aux", C.c_double * 4), ("stats", Stats)]
+
+
+class Parsed(C.Structure):
+    _fields_ = [("sense", C.c_int), ("n", C.c_int), ("m", C.c_int), ("c", dp), ("A", dp), ("rel", ip),
+                ("b", dp), ("ragged", C.c_int)]
+
+
 class LpxError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"liblpx error {code}: {msg}")
@@ -95,6 +124,23 @@ def lib() -> C.CDLL:
     L.lpx_revised_trace.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
     L.lpx_revised_solve.argtypes = [dp, C.c_int, C.c_int, dp, dp, ip, ip, dp, dp, C.c_double, C.c_int,
                                     PIVOT_CB, vp, C.POINTER(Stats)]
+    L.lpx_tableau_solution.argtypes = [vp, C.c_int, dp, dp]
+    L.lpx_multi_run.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),
+                                C.POINTER(C.c_int), C.POINTER(Stats)]
+    L.lpx_knapsack_create.argtypes = [dp, dp, C.c_int, C.c_double, C.POINTER(vp)]
+    L.lpx_knapsack_destroy.argtypes = [vp]
+    L.lpx_knapsack_destroy.restype = None
+    L.lpx_knapsack_order.argtypes = [vp, ip]
+    L.lpx_knapsack_relax_batch.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
+    L.lpx_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
+    L.lpx_default_solve_opts.restype = None
+    L.lpx_solve.argtypes = [C.POINTER(Problem), C.c_char_p, C.POINTER(SolveOpts), C.POINTER(Result)]
+    L.lpx_result_free.argtypes = [C.POINTER(Result)]
+    L.lpx_result_free.restype = None
+    L.lpx_parse_text.argtypes = [C.c_char_p, C.POINTER(Parsed)]
+    L.lpx_parsed_free.argtypes = [C.POINTER(Parsed)]
+    L.lpx_parsed_free.restype = None
+    L.lpx_format_number.argtypes = [C.c_double, C.c_char_p, C.c_int]
     _lib = L
     return L
 

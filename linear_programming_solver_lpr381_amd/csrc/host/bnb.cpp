@@ -1,0 +1,382 @@
+// host/bnb.cpp -- BranchAndBound mirror (Models/Branch&Bound.cs:20-304).
+//
+// Every node is an LP rebuilt from the root model plus its branching rows and re-solved from the
+// slack basis on the GPU, exactly as the reference re-solves through LPSolver (:148).  Two modes:
+//   faithful (bnb_mode 0)  DualSimplex keeps defects D1/D2: every `>=` child comes back without
+//                          Solution/Tableau/Basis and is dropped as "Invalid" (:157-161).
+//   repaired (bnb_mode 1)  DualSimplex runs with LPX_DUAL_REPAIRED; INFEASIBLE relaxations are pruned.
+// Two searches:
+//   bnb_search 0  the reference's recursive DFS, ceil child first (:256-257) -- node order, incumbent
+//                 and node log are those of the reference.
+//   bnb_search 1  level-synchronous frontier for the sharded node queue: the first levels are
+//                 expanded redundantly on every rank until the frontier holds >= world*concurrent
+//                 nodes, then frontier[i] belongs to rank i % world and stays local with its
+//                 subtree; per level each rank solves its node LPs `concurrent_nodes` at a time
+//                 (lpx_multi_run) and ONE all-reduce(max) over {incumbent z, have_work} is exchanged.
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace lpx { namespace host {
+
+namespace {
+
+constexpr double EPS = 1e-6;      // :24
+constexpr int MaxDepth = 200;     // :25
+
+enum Outcome { O_ERROR = 0, O_INVALID = 1, O_INFEASIBLE_X = 2, O_PRUNED = 3, O_INCUMBENT = 4, O_NO_FRAC = 5,
+               O_BRANCHED = 6, O_DEPTH = 7, O_LP_INFEASIBLE = 8 };
+
+struct Cut { int var; Rel rel; double bound; };
+
+std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b; }
+
+// pool of device tableaux keyed by shape: nodes of one depth share a shape
+struct HandlePool {
+    std::map<std::pair<int, int>, std::vector<lpx_tableau*>> free_;
+    std::vector<lpx_tableau*> all_;
+    lpx_tableau* get(int R, int C) {
+        auto& v = free_[{R, C}];
+        if (!v.empty()) { lpx_tableau* t = v.back(); v.pop_back(); return t; }
+        lpx_tableau* t = nullptr;
+        int rc = lpx_tableau_create(R, C, &t);
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        all_.push_back(t);
+        return t;
+    }
+    void put(lpx_tableau* t) { int R, C; lpx_tableau_shape(t, &R, &C, nullptr); free_[{R, C}].push_back(t); }
+    ~HandlePool() { for (lpx_tableau* t : all_) lpx_tableau_destroy(t); }
+};
+
+struct NodeLP {
+    // result of one relaxation
+    bool error = false, has_solution = false;
+    int status = LPX_OPTIMAL;
+    std::vector<double> x; double z = 0.0;
+    int64_t pivots = 0;
+    // prepared tableau
+    std::vector<double> T; int R = 0, C = 0; std::vector<int32_t> basis; bool dual = false;
+    lpx_tableau* h = nullptr;
+};
+
+struct Ctx {
+    const LPProblem* root; EngineOptions opt; UpdatePivot cb;
+    double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
+    SimplexResult* out; HandlePool pool; bool stop = false;
+    void log(const std::string& s) { if (cb) cb(s + "\n", nullptr); }
+};
+
+LPProblem make_node(const LPProblem& root, const std::vector<Cut>& cuts)
+{
+    LPProblem p = root.Clone();                                   // :233, :242
+    for (const Cut& c : cuts) {
+        Constraint k; k.A.assign(root.NumVars(), 0.0); k.A[c.var] = 1.0;   // UnitVector, :298-303
+        k.Relation = c.rel; k.B = c.bound;
+        p.Constraints.push_back(k);
+    }
+    return p;
+}
+
+bool has_ge_or_eq(const LPProblem& p)                             // ChooseAlgorithm, :262-266
+{
+    for (const Constraint& c : p.Constraints) if (c.Relation == Rel::GE || c.Relation == Rel::EQ) return true;
+    return false;
+}
+
+bool IsIntegral(const std::vector<double>& x)                     // :268-274
+{
+    for (double v : x) if (std::fabs(v - std::nearbyint(v)) > EPS) return false;
+    return true;
+}
+
+bool IsFeasible(const std::vector<double>& x, const LPProblem& problem)   // :276-294
+{
+    for (const Constraint& c : problem.Constraints) {
+        double sum = 0;
+        for (size_t i = 0; i < x.size(); ++i) sum += c.A[i] * x[i];
+        if (c.Relation == Rel::LE && sum > c.B + EPS) return false;
+        if (c.Relation == Rel::GE && sum < c.B - EPS) return false;
+        if (c.Relation == Rel::EQ && std::fabs(sum - c.B) > EPS) return false;
+    }
+    for (double v : x) if (v < -EPS) return false;
+    return true;
+}
+
+// Prepares the relaxation exactly as PrimalSimplex.Solve / DualSimplex.Solve would (exceptions of
+// the preparation become `error`, as BranchAndBound catches them, :150-154).
+void prepare(const Ctx& c, const LPProblem& p, NodeLP& lp)
+{
+    std::vector<std::string> names;
+    try {
+        lp.dual = has_ge_or_eq(p);
+        if (!lp.dual) {
+            LPProblem model = p.Clone();
+            if (model.ObjectiveSense == Sense::Min) for (double& v : model.C) v = -v;
+            for (const Constraint& k : model.Constraints)
+                if (k.B < -1e-9) { lp.error = true; return; }      // "negative RHS" exception, PrimalSimplex.cs:73-76
+            BuildTableauPrimal(ExpandEqualitiesToInequalities(model), lp.T, lp.R, lp.C, lp.basis, names);
+        } else {
+            const bool repaired = c.opt.bnb_mode == 1;
+            BuildTableauPrimal(PrepareForTableauDual(p, repaired), lp.T, lp.R, lp.C, lp.basis, names);
+        }
+    } catch (const LpxException&) { lp.error = true; }
+}
+
+void upload(Ctx& c, NodeLP& lp)
+{
+    lp.h = c.pool.get(lp.R, lp.C);
+    int rc = lpx_tableau_upload(lp.h, lp.T.data(), lp.basis.data());
+    if (rc) throw LpxException(rc, "liblpx: " + last_error());
+    std::vector<double>().swap(lp.T);
+}
+
+void collect(Ctx& c, NodeLP& lp, int status, const lpx_stats& st, int nvars)
+{
+    lp.pivots = st.pivots;
+    c.out->Stats.pivots += st.pivots; c.out->Stats.launches += st.launches; c.out->Stats.loop_ms += st.loop_ms;
+    if (status < 0) throw LpxException(status, "liblpx: " + last_error());
+    lp.status = status;
+    if (status == LPX_ITER_LIMIT) { lp.error = true; }              // exception in the reference
+    else if (lp.dual && c.opt.bnb_mode == 0) { lp.has_solution = false; }   // defect D2
+    else {
+        lp.x.assign(nvars, 0.0);
+        int rc = lpx_tableau_solution(lp.h, nvars, lp.x.data(), &lp.z);
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        lp.has_solution = true;
+    }
+    c.pool.put(lp.h); lp.h = nullptr;
+}
+
+// solves a group of prepared relaxations, `concurrent_nodes` at a time (K9)
+void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
+{
+    lpx_run_opts po, dopt; lpx_default_opts(&po, 0); lpx_default_opts(&dopt, 1);
+    po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
+    if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
+    const size_t width = (size_t)std::max(1, c.opt.concurrent_nodes);
+    for (size_t a = 0; a < group.size(); a += width) {
+        const size_t b = std::min(group.size(), a + width);
+        std::vector<lpx_tableau*> hs; std::vector<int> dual; std::vector<NodeLP*> live;
+        for (size_t i = a; i < b; ++i) {
+            NodeLP* lp = group[i];
+            if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
+            upload(c, *lp);
+            hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
+        }
+        c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
+        if (hs.empty()) continue;
+        std::vector<int> st(hs.size()); std::vector<lpx_stats> ss(hs.size());
+        int rc = lpx_multi_run(hs.data(), dual.data(), (int)hs.size(), &po, &dopt, st.data(), ss.data());
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        for (size_t i = 0; i < live.size(); ++i) collect(c, *live[i], st[i], ss[i], nvars);
+    }
+}
+
+void node_log(Ctx& c, int depth, int outcome, int var, double z)
+{
+    c.out->NodeLog.push_back(depth); c.out->NodeLog.push_back(outcome); c.out->NodeLog.push_back(var);
+    c.out->NodeZ.push_back(z);
+}
+
+void set_incumbent(Ctx& c, const std::vector<double>& x, double z)
+{
+    c.best = z; c.has_best = true;
+    c.best_x.resize(x.size());
+    for (size_t i = 0; i < x.size(); ++i) c.best_x[i] = std::nearbyint(x[i]);    // RoundInt, :296
+}
+
+// The decision part of SolveNode (:156-230) for a solved relaxation.  Returns the branching
+// variable (>= 0) when the node branches, else -1.
+int decide(Ctx& c, const LPProblem& p, const NodeLP& lp, int depth, const std::string& name, int& floorVal, int& ceilVal)
+{
+    if (lp.error) { c.log(name + ": LP relaxation infeasible or error"); node_log(c, depth, O_ERROR, -1, 0.0); return -1; }
+    if (!lp.has_solution) {
+        c.log(name + ": Invalid Simplex result (missing Solution, Tableau, Basis, or VarNames).");
+        node_log(c, depth, O_INVALID, -1, 0.0); return -1;
+    }
+    if (c.opt.bnb_mode == 1 && lp.status == LPX_INFEASIBLE) { node_log(c, depth, O_LP_INFEASIBLE, -1, lp.z); return -1; }
+    const std::vector<double>& x = lp.x; const double z = lp.z;
+    if (c.cb) c.log(name + " LP solution: z* = " + FormatF(z, 3));
+    if (!IsFeasible(x, p)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
+    const double bestObj = c.has_best ? c.best : -INFINITY;
+    if (z <= bestObj + EPS) { c.log(name + ": Pruned by bound (z* <= current best " + FormatF(bestObj, 3) + ")."); node_log(c, depth, O_PRUNED, -1, z); return -1; }   // :182-186
+    if (IsIntegral(x)) {                                                     // :189-195
+        set_incumbent(c, x, z);
+        c.log(name + " is integer feasible. Updated BestObjective = " + FormatF(z, 3));
+        node_log(c, depth, O_INCUMBENT, -1, z); return -1;
+    }
+    int fracIndex = -1; double minDist = 1.7976931348623157e308;             // :198-213
+    for (int i = 0; i < (int)x.size(); ++i) {
+        double fracPart = x[i] - std::floor(x[i]);
+        if (fracPart > EPS && (1 - fracPart) > EPS) {
+            double dist = std::fabs(fracPart - 0.5);
+            if (dist < minDist || (dist == minDist && i < fracIndex)) { minDist = dist; fracIndex = i; }
+        }
+    }
+    if (fracIndex == -1) { node_log(c, depth, O_NO_FRAC, -1, z); return -1; }  // :215-219
+    floorVal = (int)std::floor(x[fracIndex]);                                // :222-223
+    ceilVal = (int)std::ceil(x[fracIndex]);
+    c.log(name + ": Branching on x" + std::to_string(fracIndex + 1) + " = " + FormatF(x[fracIndex], 3) +
+          " (floor=" + std::to_string(floorVal) + ", ceil=" + std::to_string(ceilVal) + ")");
+    node_log(c, depth, O_BRANCHED, fracIndex, z);
+    return fracIndex;
+}
+
+// ---- search 0: the reference's recursion (:128-258) ---------------------------------------------------
+void SolveNode(Ctx& c, std::vector<Cut>& cuts, int depth, const std::string& name)
+{
+    if (c.stop) return;
+    if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { c.stop = true; return; }
+    c.out->Nodes++;
+    if (depth > MaxDepth) { c.log(name + ": Maximum recursion depth reached -> prune."); node_log(c, depth, O_DEPTH, -1, 0.0); return; }
+    LPProblem p = make_node(*c.root, cuts);
+    NodeLP lp; prepare(c, p, lp);
+    std::vector<NodeLP*> g{&lp};
+    solve_group(c, g, p.NumVars());
+    int fl = 0, ce = 0;
+    int k = decide(c, p, lp, depth, name, fl, ce);
+    if (k < 0) return;
+    cuts.push_back({k, Rel::GE, (double)ce});
+    SolveNode(c, cuts, depth + 1, "Subproblem: x" + std::to_string(k + 1) + " >= " + std::to_string(ce));   // ceil first, :256
+    cuts.back() = {k, Rel::LE, (double)fl};
+    SolveNode(c, cuts, depth + 1, "Subproblem: x" + std::to_string(k + 1) + " <= " + std::to_string(fl));   // :257
+    cuts.pop_back();
+}
+
+// ---- search 1: level-synchronous frontier -----------------------------------------------------------
+struct FNode { std::vector<Cut> cuts; int depth; };
+
+void LevelSearch(Ctx& c)
+{
+    const int world = std::max(1, c.opt.world), rank = c.opt.rank;
+    const size_t want = (size_t)world * (size_t)std::max(1, c.opt.concurrent_nodes);
+    std::vector<FNode> frontier{FNode{{}, 0}};
+    bool replicated = world > 1;
+    for (;;) {
+        if (replicated && frontier.size() >= want) {
+            // hand the replicated frontier out: node i -> rank i % world, subtrees stay local from here on
+            std::vector<FNode> mine;
+            for (size_t i = 0; i < frontier.size(); ++i) if ((int)(i % world) == rank) mine.push_back(std::move(frontier[i]));
+            frontier.swap(mine);
+            replicated = false;
+        }
+        // solve this level
+        std::vector<LPProblem> probs; probs.reserve(frontier.size());
+        std::vector<NodeLP> lps(frontier.size());
+        std::vector<NodeLP*> group;
+        std::vector<char> skip(frontier.size(), 0);
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            probs.push_back(make_node(*c.root, frontier[i].cuts));
+            if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
+            c.out->Nodes++;
+            if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
+            prepare(c, probs[i], lps[i]);
+            group.push_back(&lps[i]);
+        }
+        solve_group(c, group, c.root->NumVars());
+        std::vector<FNode> next;
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            if (skip[i] == 1) continue;
+            if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
+            int fl = 0, ce = 0;
+            int k = decide(c, probs[i], lps[i], frontier[i].depth, "Node", fl, ce);
+            if (k < 0) continue;
+            FNode up{frontier[i].cuts, frontier[i].depth + 1}; up.cuts.push_back({k, Rel::GE, (double)ce});
+            FNode dn{frontier[i].cuts, frontier[i].depth + 1}; dn.cuts.push_back({k, Rel::LE, (double)fl});
+            next.push_back(std::move(up));                                   // ceil child first
+            next.push_back(std::move(dn));
+        }
+        frontier.swap(next);
+        // one all-reduce(max) per level: incumbent bound and "someone still has work"
+        double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
+        if (!replicated && world > 1 && c.opt.allreduce_max) {
+            const double mine = vals[0];
+            c.opt.allreduce_max(vals, 2);
+            if (vals[0] > mine + 0.0) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); } }
+        }
+        if (vals[1] == 0.0) break;
+    }
+    if (world > 1 && c.opt.allreduce_max) {
+        // final ownership: lowest rank holding x for the global best publishes it (MAX of -rank, then MAX of x)
+        double own = (c.has_best && !c.best_x.empty()) ? -(double)rank : -INFINITY;
+        c.opt.allreduce_max(&own, 1);
+        const int n = c.root->NumVars();
+        std::vector<double> xs(n, -INFINITY);
+        if (own == -(double)rank && c.has_best && !c.best_x.empty()) xs = c.best_x;
+        if (own != -INFINITY) { c.opt.allreduce_max(xs.data(), n); c.best_x = xs; }
+    }
+}
+
+}  // namespace
+
+// BranchAndBound.Solve, Models/Branch&Bound.cs:30-123
+SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot updatePivot)
+{
+    BestObjective = -INFINITY; BestSolution.clear(); HasBest = false;
+    SimplexResult out;
+    Ctx c; c.root = &problem; c.opt = opt; c.cb = updatePivot; c.out = &out;
+    c.log("=== Branch & Bound Algorithm ===");
+    const char* rootAlgo = has_ge_or_eq(problem) ? "Dual Simplex" : "Primal Simplex";     // :50
+    c.log(std::string("Branch & Bound: Using ") + rootAlgo + " for the ROOT LP relaxation.");
+
+    EngineOptions lopt = opt; lopt.dual_flags = opt.bnb_mode == 1 ? LPX_DUAL_REPAIRED : 0;
+    LPSolver solver(lopt);
+    SimplexResult rootRes;
+    out.LpSolves = 1;
+    try {
+        rootRes = solver.Solve(problem, rootAlgo, nullptr);                               // :57
+    } catch (const LpxException& ex) {
+        if (ex.code == LPX_EDEVICE || ex.code == LPX_ENOMEM) throw;
+        c.log(std::string("Root Problem: LP relaxation infeasible or error: ") + ex.what());
+        out.Report = "LP relaxation infeasible"; out.Summary = "Error: Infeasible"; out.Status = LPX_INFEASIBLE;
+        return out;                                                                       // :59-63
+    }
+    out.Stats.pivots += rootRes.Stats.pivots;
+    if (!rootRes.HasSolution) {                                                           // :66-70
+        c.log("Root Problem: Invalid Simplex result (missing Solution, Tableau, Basis, or VarNames).");
+        out.Report = "Invalid Simplex result"; out.Summary = "Error: Invalid result"; out.Status = LPX_INFEASIBLE;
+        return out;
+    }
+    std::vector<double> xRoot(rootRes.Solution.begin(), rootRes.Solution.begin() + std::min<size_t>(rootRes.Solution.size(), problem.NumVars()));
+    const double zRoot = rootRes.OptimalValue;
+    c.log("Root Problem LP solution: z* = " + FormatF(zRoot, 3));
+
+    auto BuildReport = [&]() {                                                            // :99-122
+        std::string sb = "Branch & Bound Finished.\n";
+        if (!c.has_best) sb += "No integer-feasible solution found.\n";
+        else {
+            sb += "Best integer z* = " + FormatF(c.best, 3) + "\n";
+            sb += "Best integer x* = [";
+            for (size_t i = 0; i < c.best_x.size(); ++i) { if (i) sb += ", "; sb += FormatF(c.best_x[i], 3); }
+            sb += "]\n";
+        }
+        out.Report = sb; out.Summary = sb;
+        out.OptimalValue = c.has_best ? c.best : -INFINITY;
+        out.Solution = c.best_x; out.HasSolution = true;
+        out.Tableau = rootRes.Tableau; out.R = rootRes.R; out.C = rootRes.C;
+        out.Basis = rootRes.Basis; out.VarNames = rootRes.VarNames;
+        out.Status = c.has_best ? LPX_OPTIMAL : LPX_INFEASIBLE;
+        BestObjective = out.OptimalValue; BestSolution = c.best_x; HasBest = c.has_best;
+    };
+
+    if (IsIntegral(xRoot) && IsFeasible(xRoot, problem)) {                                // :85-91
+        set_incumbent(c, xRoot, zRoot);
+        c.log("Root Problem is already integral and feasible. Branch & Bound not required.");
+        BuildReport();
+        return out;
+    }
+    c.log("Root solution is fractional -> starting Branch & Bound.");
+    if (opt.bnb_search == 0) {
+        std::vector<Cut> cuts;
+        SolveNode(c, cuts, 0, "Root Problem");                                            // :95 (root solved a second time)
+    } else {
+        LevelSearch(c);
+    }
+    BuildReport();
+    return out;
+}
+
+}}  // namespace lpx::host

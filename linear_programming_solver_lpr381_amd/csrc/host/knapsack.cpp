@@ -1,0 +1,286 @@
+// host/knapsack.cpp -- BranchAndBoundKnapsack mirror (Models/BranchAndBoundKnapsack.cs:58-407).
+//
+// The search is the reference's: best-first on the greedy fractional bound with its own array heap
+// (Push sift-up breaks on `<= 0`, Pop swaps the last element in and sifts down, :494-547), left child
+// (x=0) evaluated before right child (x=1), incumbent rule `> best + 1e-9`.  What moves to the GPU is
+// ComputeRelaxation: the children of the node being expanded AND of the next `spec` nodes near the top
+// of the heap are evaluated in ONE lpx_knapsack_relax_batch launch and cached on the nodes, so the
+// host replays the exact reference order while the device sees batches.  A relaxation depends only on
+// the node's fixed set, never on the search order, so caching cannot change any decision.
+// Report text (3n lines per expansion, :139-143) is not produced.
+//
+// Sharded form (world > 1): the tree is expanded redundantly until the heap holds >= 4*world nodes,
+// heap[i] then belongs to rank i % world; every rank runs the same best-first loop on its own heap for
+// `round` pops, then ONE all-reduce(max) over {incumbent, have_work} (X1) and the loop continues.
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace lpx { namespace host {
+
+namespace {
+
+constexpr double EPS = 1e-9;          // :56
+
+std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b; }
+
+struct Relax { double profit = 0, weight = 0, fracval = 0; int frac = -1; bool valid = false; };
+
+struct KNode {
+    std::vector<int32_t> idx; std::vector<int8_t> val;      // decisions in branching order
+    double bound = 0; Relax self;                          // own relaxation (bound == self.profit)
+    Relax child[2];                                        // cached children (x=0, x=1)
+};
+using NodeP = std::unique_ptr<KNode>;
+
+struct Heap {                                              // SimpleMaxHeap<Node>, :494-547
+    std::vector<KNode*> d;
+    static int cmp(const KNode* a, const KNode* b) { return (a->bound > b->bound) - (a->bound < b->bound); }
+    void push(KNode* x) {
+        d.push_back(x);
+        size_t ci = d.size() - 1;
+        while (ci > 0) { size_t pi = (ci - 1) / 2; if (cmp(d[ci], d[pi]) <= 0) break; std::swap(d[ci], d[pi]); ci = pi; }
+    }
+    KNode* pop() {
+        size_t li = d.size() - 1;
+        std::swap(d[0], d[li]);
+        KNode* ret = d[li]; d.pop_back();
+        if (d.empty()) return ret;
+        li = d.size() - 1;
+        size_t i = 0;
+        for (;;) {
+            size_t l = 2 * i + 1, r = 2 * i + 2, largest = i;
+            if (l <= li && cmp(d[l], d[largest]) > 0) largest = l;
+            if (r <= li && cmp(d[r], d[largest]) > 0) largest = r;
+            if (largest == i) break;
+            std::swap(d[i], d[largest]); i = largest;
+        }
+        return ret;
+    }
+};
+
+struct Search {
+    lpx_knapsack* k; int n; double cap;
+    std::vector<double> profit, weight; std::vector<int32_t> order;
+    double best = -INFINITY; std::vector<int32_t> bestX; bool has_best = false;
+    int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0;
+    int spec = 64;
+
+    // evaluates `jobs` = (node, fixed item, value) in one launch
+    struct Job { KNode* node; int item; int v; Relax* out; };
+    void run_jobs(std::vector<Job>& jobs)
+    {
+        if (jobs.empty()) return;
+        std::vector<int32_t> off(jobs.size() + 1, 0), fidx; std::vector<int8_t> fval;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const KNode* nd = jobs[j].node;
+            std::vector<std::pair<int32_t, int8_t>> f;
+            for (size_t e = 0; e < nd->idx.size(); ++e) f.emplace_back(nd->idx[e], nd->val[e]);
+            if (jobs[j].item >= 0) f.emplace_back(jobs[j].item, (int8_t)jobs[j].v);
+            std::sort(f.begin(), f.end());                  // original index ascending (:442)
+            for (auto& pr : f) { fidx.push_back(pr.first); fval.push_back(pr.second); }
+            off[j + 1] = (int32_t)fidx.size();
+        }
+        std::vector<double> p(jobs.size()), w(jobs.size()), fv(jobs.size()); std::vector<int32_t> fr(jobs.size());
+        if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
+        int rc = lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        ++launches;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            Relax& r = *jobs[j].out;
+            r.profit = p[j]; r.weight = w[j]; r.frac = fr[j]; r.fracval = fv[j]; r.valid = true;
+        }
+    }
+
+    // relaxed vector of a node (host, O(n); only on incumbent updates)
+    std::vector<double> relaxed_of(const KNode& nd, int item, int v, const Relax& r) const
+    {
+        std::vector<int8_t> as(n, -1);
+        for (size_t e = 0; e < nd.idx.size(); ++e) as[nd.idx[e]] = nd.val[e];
+        if (item >= 0) as[item] = (int8_t)v;
+        std::vector<double> x(n, 0.0);
+        for (int i = 0; i < n; ++i) if (as[i] == 1) x[i] = 1.0;
+        double fixedw = 0; for (int i = 0; i < n; ++i) if (as[i] == 1) fixedw += weight[i];
+        if (fixedw > cap + EPS) return x;                   // :455-456
+        const int stop = r.frac >= 0 ? r.frac : n;
+        // items before the break in ratio order that are undecided were taken whole; when there is no
+        // fractional item the greedy may still have stopped early (remain <= EPS): replay it
+        double w = fixedw;
+        for (int s = 0; s < n; ++s) {
+            const int o = order[s];
+            if (as[o] != -1) continue;
+            if (s == stop) { x[o] = r.fracval; break; }
+            if (w + weight[o] <= cap + EPS) { x[o] = 1.0; w += weight[o]; } else break;
+        }
+        return x;
+    }
+
+    void consider_child(Heap& pq, std::vector<NodeP>& store, KNode* node, int item, int v)
+    {
+        const Relax& r = node->child[v];
+        if (r.weight > cap + EPS) return;                                   // :215 / :277 INFEASIBLE
+        if (r.profit > best + EPS) {                                        // :223 / :285
+            const bool allInt = (r.frac < 0) || std::fabs(r.fracval - std::nearbyint(r.fracval)) < EPS;
+            const bool feasible = r.weight <= cap + EPS;
+            if (allInt && feasible) {                                       // :228-236
+                if (r.profit > best + EPS) {
+                    best = r.profit; has_best = true;
+                    std::vector<double> x = relaxed_of(*node, item, v, r);
+                    bestX.assign(n, 0);
+                    for (int i = 0; i < n; ++i) bestX[i] = (int32_t)std::nearbyint(x[i]);
+                }
+            } else {                                                        // :239-248
+                NodeP ch(new KNode());
+                ch->idx = node->idx; ch->val = node->val;
+                ch->idx.push_back(item); ch->val.push_back((int8_t)v);
+                ch->bound = r.profit; ch->self = r;
+                pq.push(ch.get());
+                store.push_back(std::move(ch));
+                max_heap = std::max<int64_t>(max_heap, (int64_t)pq.d.size());
+            }
+        }
+        // else: logged as "CANDIDATE" and dropped (:257-264)
+    }
+
+    // one pop of the main loop (:118-328); returns false when the heap is empty
+    bool step(Heap& pq, std::vector<NodeP>& store)
+    {
+        if (pq.d.empty()) return false;
+        KNode* node = pq.pop();
+        ++popped;                                                           // :121
+        if (node->bound <= best + EPS) return true;                         // :124
+        ++expanded;
+        ++relaxations;                                                      // :127 recompute (identical to the cached one)
+        const Relax& self = node->self;
+        if (self.frac == -1) {                                              // :147-177
+            if (self.weight <= cap + EPS && self.profit > best + EPS) {
+                best = self.profit; has_best = true;
+                std::vector<double> x = relaxed_of(*node, -1, 0, self);
+                bestX.assign(n, 0);
+                for (int i = 0; i < n; ++i) bestX[i] = x[i] >= 0.5 ? 1 : 0;
+            }
+            return true;
+        }
+        const int item = order[self.frac];                                  // :180
+        if (!node->child[0].valid || !node->child[1].valid) {
+            // one launch: this node's children plus those of the nodes near the top of the heap
+            std::vector<Job> jobs;
+            jobs.push_back({node, item, 0, &node->child[0]});
+            jobs.push_back({node, item, 1, &node->child[1]});
+            const size_t lim = std::min<size_t>(pq.d.size(), (size_t)spec);
+            for (size_t i = 0; i < lim; ++i) {
+                KNode* o = pq.d[i];
+                if (o->child[0].valid || o->self.frac < 0 || o->bound <= best + EPS) continue;
+                const int it = order[o->self.frac];
+                jobs.push_back({o, it, 0, &o->child[0]});
+                jobs.push_back({o, it, 1, &o->child[1]});
+            }
+            run_jobs(jobs);
+        }
+        relaxations += 2;
+        consider_child(pq, store, node, item, 0);                           // LEFT  x=0, :207-264
+        consider_child(pq, store, node, item, 1);                           // RIGHT x=1, :267-327
+        return true;
+    }
+};
+
+}  // namespace
+
+SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivot updatePivot)
+{
+    if (problem.Constraints.size() != 1)                                    // :66-67
+        throw LpxException(LPX_E_KNAP_SHAPE, "Knapsack solver requires exactly one constraint (weights and capacity).");
+    const Constraint& cons = problem.Constraints[0];
+    if (cons.Relation != Rel::LE) throw LpxException(LPX_E_KNAP_SHAPE, "Knapsack solver requires a <= constraint.");   // :69
+    const int n = problem.NumVars();
+    if ((int)cons.A.size() < n) throw LpxException(LPX_EINVAL, "Index was outside the bounds of the array.");
+    if (n < 1) throw LpxException(LPX_EINVAL, "Knapsack solver needs at least one item.");
+
+    Search S;
+    S.n = n; S.cap = cons.B; S.profit = problem.C; S.weight.assign(cons.A.begin(), cons.A.begin() + n);
+    lpx_knapsack* kh = nullptr;
+    int rc = lpx_knapsack_create(S.profit.data(), S.weight.data(), n, S.cap, &kh);
+    if (rc) throw LpxException(rc, "liblpx: " + last_error());
+    struct Guard { lpx_knapsack* k; ~Guard() { lpx_knapsack_destroy(k); } } guard{kh};
+    S.k = kh;
+    S.order.resize(n);
+    lpx_knapsack_order(kh, S.order.data());
+    S.bestX.assign(n, 0);
+    S.spec = opt.concurrent_nodes > 1 ? opt.concurrent_nodes : 64;
+
+    std::vector<NodeP> store;
+    Heap pq;
+    NodeP root(new KNode());                                                // :102-113
+    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self}}; S.run_jobs(j); S.relaxations++; }
+    root->bound = root->self.profit;
+    pq.push(root.get()); store.push_back(std::move(root));
+    S.max_heap = 1;
+
+    const int world = std::max(1, opt.world), rank = opt.rank;
+    const int64_t cap_nodes = opt.max_nodes;
+    bool replicated = world > 1;
+    const int round = 256;
+    for (;;) {
+        if (replicated && pq.d.size() >= (size_t)(4 * world)) {
+            Heap mine;
+            for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i]);
+            pq.d.swap(mine.d);
+            replicated = false;
+        }
+        bool more = true;
+        for (int it = 0; it < round && more; ++it) {
+            if (cap_nodes > 0 && S.popped >= cap_nodes) { more = false; break; }
+            more = S.step(pq, store);
+            if (replicated && pq.d.size() >= (size_t)(4 * world)) break;
+        }
+        if (world > 1 && !replicated && opt.allreduce_max) {
+            double vals[2] = {S.has_best ? S.best : -INFINITY, (more && !pq.d.empty()) ? 1.0 : 0.0};
+            const double mine = vals[0];
+            opt.allreduce_max(vals, 2);                                     // X1: incumbent + termination
+            if (vals[0] > mine) { S.best = vals[0]; S.has_best = true; std::fill(S.bestX.begin(), S.bestX.end(), -1); }
+            if (vals[1] == 0.0) break;
+        } else if (!more || pq.d.empty()) {
+            if (cap_nodes > 0 && S.popped >= cap_nodes) break;
+            if (pq.d.empty()) break;
+        }
+    }
+    if (world > 1 && opt.allreduce_max) {
+        double own = (S.has_best && !S.bestX.empty() && S.bestX[0] >= 0) ? -(double)rank : -INFINITY;
+        opt.allreduce_max(&own, 1);
+        std::vector<double> xs(n, -INFINITY);
+        if (own == -(double)rank && S.has_best && S.bestX[0] >= 0) for (int i = 0; i < n; ++i) xs[i] = S.bestX[i];
+        if (own != -INFINITY) { opt.allreduce_max(xs.data(), n); for (int i = 0; i < n; ++i) S.bestX[i] = (int32_t)xs[i]; }
+    }
+
+    // final report, :368-405 ("Report = finalReport, Summary = \"\"")
+    std::string fr = "Final Report:\nBranch & Bound Knapsack Finished.\n\n";
+    if (!S.has_best) fr += "Status: INFEASIBLE\n";
+    else {
+        fr += "Status: BEST CANDIDATE FOUND\n";
+        for (int i = 0; i < n && n <= 4096; ++i) fr += "  x" + std::to_string(i + 1) + " = " + std::to_string(S.bestX[i]) + "\n";
+        fr += "  z* = " + FormatNumber(S.best) + "\n";
+    }
+    fr += "\nSummary:\n";
+    if (!S.has_best) fr += "No feasible candidate found.\n";
+    else {
+        fr += "Best Candidate = " + FormatNumber(S.best) + "\n";
+        if (n <= 4096) { fr += "Best x* = ["; for (int i = 0; i < n; ++i) { if (i) fr += ", "; fr += std::to_string(S.bestX[i]); } fr += "]\n"; }
+    }
+    if (updatePivot) updatePivot(fr, nullptr);
+    SimplexResult res;
+    res.Report = fr; res.Summary = "";
+    res.Status = S.has_best ? LPX_OPTIMAL : LPX_INFEASIBLE;
+    // The reference returns text only; engine extras:
+    res.OptimalValue = S.has_best ? S.best : -INFINITY;
+    res.Solution.assign(S.bestX.begin(), S.bestX.end());
+    res.HasSolution = false;
+    res.Nodes = S.popped; res.LpSolves = S.relaxations;
+    res.NodeZ = {(double)S.relaxations, (double)S.popped, (double)S.expanded, (double)S.max_heap};
+    res.Stats.launches = S.launches;
+    return res;
+}
+
+}}  // namespace lpx::host

@@ -1,0 +1,157 @@
+// host/model.h -- C++ mirror of the reference's plugin boundary: data model, ILPAlgorithm,
+// LPSolver (Models/PrimalSimplex.cs:8-49, Models/IPLAlgorithm.cs:5-8, Models/LPSolver.cs:16-76).
+// Same names, argument meaning and error behaviour as the C# so that tests read like tests of the
+// reference; the loops themselves run on the GPU through the C ABI (include/lpx.h).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/lpx.h"
+
+namespace lpx { namespace host {
+
+enum class Sense { Max, Min };          // Models/PrimalSimplex.cs:8
+enum class Rel { LE, GE, EQ };          // Models/PrimalSimplex.cs:9
+
+struct Constraint {                     // Models/PrimalSimplex.cs:11-18
+    std::vector<double> A;
+    Rel Relation = Rel::LE;
+    double B = 0.0;
+};
+
+struct LPProblem {                      // Models/PrimalSimplex.cs:20-36
+    Sense ObjectiveSense = Sense::Max;
+    std::vector<double> C;
+    std::vector<Constraint> Constraints;
+    int NumVars() const { return (int)C.size(); }
+    LPProblem Clone() const { return *this; }
+};
+
+// bool[,] highlight of the reference callback: row-major R x C flags (empty = null)
+struct Highlight { int R = 0, C = 0; std::vector<uint8_t> cells; };
+// Action<string, bool[,]> updatePivot (Models/IPLAlgorithm.cs:7)
+using UpdatePivot = std::function<void(const std::string& text, const Highlight* highlight)>;
+
+struct SimplexResult {                  // Models/PrimalSimplex.cs:38-49
+    std::string Report, Summary;
+    double OptimalValue = 0.0;
+    bool HasSolution = false;           // false == Solution/Tableau/Basis/VarNames are null (defect D2)
+    std::vector<double> Solution;
+    std::vector<double> Tableau; int R = 0, C = 0;      // row-major R x C
+    std::vector<int32_t> Basis;
+    std::vector<std::string> VarNames;
+    // additions of this engine (not in the reference record)
+    int Status = LPX_OPTIMAL;           // LPX_OPTIMAL / LPX_UNBOUNDED / LPX_INFEASIBLE
+    std::vector<int32_t> Trace;         // (leaving row, entering column) per pivot
+    lpx_stats Stats{};
+    int64_t LpSolves = 0, Nodes = 0;    // branch-and-bound counters
+    std::vector<int32_t> NodeLog;       // B&B: (depth, outcome, branching var) per visited node
+    std::vector<double> NodeZ;
+};
+
+// The reference throws System.Exception with fixed messages; `code` is the LPX_E_* of include/lpx.h.
+struct LpxException : std::runtime_error {
+    int code;
+    LpxException(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct ILPAlgorithm {                   // Models/IPLAlgorithm.cs:5-8
+    virtual ~ILPAlgorithm() = default;
+    virtual SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) = 0;
+};
+
+// Engine knobs that have no counterpart in the reference (all default to reference behaviour).
+struct EngineOptions {
+    bool render_iterations = false;  // true: format the whole tableau for every pivot callback as the
+                                     // reference does (Models/PrimalSimplex.cs:113-121); needs one
+                                     // download per pivot.  false: callbacks get one line per pivot.
+    int batch = 0;                   // pivots per host poll (0 = library default)
+    int dual_flags = 0;              // 0 faithful (D1/D2 kept); LPX_DUAL_REPAIRED = repaired
+    int bnb_mode = 0;                // 0 faithful, 1 repaired
+    int bnb_search = 0;              // 0 = reference DFS (ceil first), 1 = level-synchronous sharded
+    int64_t max_nodes = 0;           // 0 = unlimited
+    int concurrent_nodes = 1;        // level-synchronous search: node LPs in flight per GPU
+    int rank = 0, world = 1;         // level-synchronous search: shard of this process
+    // incumbent exchange: called once per level with {best_z, have_work}; must return the MAX over
+    // ranks in place (RCCL all-reduce in production, identity for one process).
+    std::function<void(double* vals, int count)> allreduce_max;
+    int max_iter = 10000;
+};
+
+enum { LPX_DUAL_FIX_D1 = 1, LPX_DUAL_FIX_D2 = 2, LPX_DUAL_SOUND = 4, LPX_DUAL_REPAIRED = 7 };
+
+class PrimalSimplex : public ILPAlgorithm {             // Models/PrimalSimplex.cs:52-305
+public:
+    explicit PrimalSimplex(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& original, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+class DualSimplex : public ILPAlgorithm {               // Models/DualSimplex.cs:11-313
+public:
+    explicit DualSimplex(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& original, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+class RevisedPrimalSimplex : public ILPAlgorithm {      // Models/RevisedPrimalSimplex.cs:12-458
+public:
+    explicit RevisedPrimalSimplex(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& original, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+class BranchAndBound : public ILPAlgorithm {            // Models/Branch&Bound.cs:20-304
+public:
+    explicit BranchAndBound(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) override;
+    double BestObjective = -1.0 / 0.0;
+    std::vector<double> BestSolution; bool HasBest = false;
+private:
+    EngineOptions opt;
+};
+
+class BranchAndBoundKnapsack : public ILPAlgorithm {    // Models/BranchAndBoundKnapsack.cs:12-548
+public:
+    explicit BranchAndBoundKnapsack(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+class LPSolver {                                        // Models/LPSolver.cs:6-77
+public:
+    explicit LPSolver(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, const std::string& algorithm, UpdatePivot updatePivot = nullptr);
+    static std::string NormalizeAlgorithmKey(const std::string& algorithm);   // :61-76
+    std::vector<double> FinalTableau; int FinalR = 0, FinalC = 0; bool HasFinalTableau = false;   // :11
+private:
+    EngineOptions opt;
+};
+
+// LPParser.ParseFromText, Models/LPParser.cs:9-79.  Throws LpxException(LPX_E_PARSE, message).
+LPProblem ParseFromText(const std::string& input);
+
+// Text formats of the reference (Models/PrimalSimplex.cs:259-304 and friends), see format.cpp
+std::string FormatNumber(double v);                 // ToString("0.###")
+std::string FormatF(double v, int decimals);        // ToString("F3"/"F6", InvariantCulture)
+std::string FormatRound3(double v);                 // $"{Math.Round(v, 3):0.###}"
+double RoundHalfEven(double v, int decimals);       // Math.Round(v, decimals)
+std::string AppendTableau(const std::string& title, const double* T, int R, int C,
+                          const std::vector<int32_t>& basis, const std::vector<std::string>& varNames, int iter);
+std::string AppendCanonicalForm(const LPProblem& model);
+
+// helpers shared by the solver mirrors (solvers.cpp)
+void BuildTableauPrimal(const LPProblem& expanded, std::vector<double>& T, int& R, int& C,
+                        std::vector<int32_t>& basis, std::vector<std::string>& varNames);
+LPProblem ExpandEqualitiesToInequalities(const LPProblem& model);
+LPProblem PrepareForTableauDual(const LPProblem& original, bool fix_d1);
+
+}}  // namespace lpx::host

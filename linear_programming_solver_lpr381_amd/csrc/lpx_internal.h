@@ -82,6 +82,25 @@ struct LoopCtx {
 int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
                     lpx_pivot_cb cb, void* user, lpx_stats* stats);
 
+// Resumable form of the same loop: begin(); { submit(); complete(); } until done(); finish().
+// submit() only enqueues (one batch + an async copy of the state to pinned memory), so several
+// runs on different streams overlap on the device (lpx_multi_run).
+class LoopRun {
+public:
+    int begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
+              lpx_pivot_cb cb, void* user);
+    int submit();
+    int complete();
+    bool done() const { return status_ != LPX_RUNNING || enq_ >= budget_; }
+    int finish(lpx_stats* stats);          // returns the final status (or an error)
+private:
+    LoopCtx c_; lpx_run_opts o_{}; long long budget_ = 0, enq_ = 0;
+    lpx_pivot_cb cb_ = nullptr; void* user_ = nullptr;
+    lpx_stats local_{}; int batch_ = 64; bool graph_ = false;
+    int fired_ = 0, iter_before_ = 0, status_ = LPX_RUNNING, init_phase_ = 2;
+    double t0_ = 0;
+};
+
 }  // namespace lpx
 
 #define LPX_HIP_TRY(expr)                                                                  \

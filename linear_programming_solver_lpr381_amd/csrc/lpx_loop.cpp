@@ -65,81 +65,106 @@ static int build_graph(LoopCtx& c, int batch)
     return 0;
 }
 
-// Runs iterations until the device state leaves LPX_RUNNING.  `budget` bounds the number of
-// iterations ever enqueued (each one either pivots, changes phase, or terminates).
+// ---------------------------------------------------------------------------------------------------
+// LoopRun: iterations are enqueued batch-wise until the device state leaves LPX_RUNNING.  `budget`
+// bounds the number of iterations ever enqueued (each one pivots, changes phase, or terminates).
+// ---------------------------------------------------------------------------------------------------
+int LoopRun::begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
+                   lpx_pivot_cb cb, void* user)
+{
+    c_ = c; o_ = *o; budget_ = budget; cb_ = cb; user_ = user;
+    enq_ = 0; fired_ = 0; status_ = LPX_RUNNING; init_phase_ = init.phase;
+    std::memset(&local_, 0, sizeof(local_));
+    batch_ = o_.batch > 0 ? o_.batch : 64;
+    if (o_.profile && batch_ > 256) batch_ = 256;
+    graph_ = o_.use_graph && !o_.profile;
+    *c_.hst = init;                                 // pinned staging: safe for the async copy below
+    LPX_HIP_TRY(hipMemcpyAsync(c_.st, c_.hst, sizeof(DevState), hipMemcpyHostToDevice, c_.stream));
+    LPX_HIP_TRY(hipStreamSynchronize(c_.stream));
+    if (o_.profile) {
+        size_t need = 2 * (size_t)batch_;
+        while (c_.events->size() < need) {
+            hipEvent_t e;
+            LPX_HIP_TRY(hipEventCreate(&e));
+            c_.events->push_back(e);
+        }
+    }
+    if (graph_) { int rc = build_graph(c_, batch_); if (rc) return rc; }
+    t0_ = now_ms();
+    if (c_.prologue) { int rc = c_.prologue(c_.stream); if (rc) return rc; local_.launches += 1; }
+    return 0;
+}
+
+int LoopRun::submit()
+{
+    iter_before_ = fired_;
+    if (graph_) {
+        LPX_HIP_TRY(hipGraphLaunch(*c_.gexec, c_.stream));
+    } else {
+        for (int i = 0; i < batch_; ++i) {
+            int rc = o_.profile ? c_.enqueue_iter(c_.stream, (*c_.events)[2 * i], (*c_.events)[2 * i + 1])
+                                : c_.enqueue_iter(c_.stream, nullptr, nullptr);
+            if (rc) return rc;
+        }
+    }
+    enq_ += batch_;
+    local_.launches += (long long)c_.launches_per_iter * batch_;
+    LPX_HIP_TRY(hipMemcpyAsync(c_.hst, c_.st, sizeof(DevState), hipMemcpyDeviceToHost, c_.stream));
+    return 0;
+}
+
+int LoopRun::complete()
+{
+    LPX_HIP_TRY(hipStreamSynchronize(c_.stream));
+    status_ = c_.hst->status;
+    const int done = c_.hst->iter;
+    if (o_.profile && c_.profile_maps) {
+        // the first (done - iter_before) iterations of this batch each ran one full update
+        const int full = done - iter_before_;
+        for (int i = 0; i < full && i < batch_; ++i) {
+            float ms = 0.f;
+            LPX_HIP_TRY(hipEventElapsedTime(&ms, (*c_.events)[2 * i], (*c_.events)[2 * i + 1]));
+            local_.update_ms_sum += ms;
+            local_.update_launches++;
+        }
+    }
+    if (cb_ && done > fired_) {
+        int lo = fired_, hi = done < c_.trace_cap ? done : c_.trace_cap;
+        if (hi > lo) {
+            std::vector<int32_t> tr(2 * (size_t)(hi - lo));
+            LPX_HIP_TRY(hipMemcpy(tr.data(), c_.trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
+            for (int k = lo; k < hi; ++k) cb_(user_, k + 1, tr[2 * (k - lo)], tr[2 * (k - lo) + 1]);
+        }
+    }
+    fired_ = done;
+    return 0;
+}
+
+int LoopRun::finish(lpx_stats* stats)
+{
+    local_.loop_ms = now_ms() - t0_;
+    local_.pivots = c_.hst->iter;
+    local_.fdf_pivots = c_.hst->fdf_count;
+    local_.cleanup_pivots = (init_phase_ == 0) ? c_.hst->primal_count : 0;
+    if (stats) {
+        double h2d = stats->h2d_ms, d2h = stats->d2h_ms;
+        *stats = local_; stats->h2d_ms = h2d; stats->d2h_ms = d2h;
+    }
+    if (status_ == LPX_RUNNING) { set_error("loop budget exhausted while still running"); return LPX_ITER_LIMIT; }
+    return status_;
+}
+
 int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
                     lpx_pivot_cb cb, void* user, lpx_stats* stats)
 {
-    int batch = o->batch > 0 ? o->batch : 64;
-    if (o->profile && batch > 256) batch = 256;
-    const bool graph = o->use_graph && !o->profile;
-    lpx_stats local; std::memset(&local, 0, sizeof(local));
-
-    LPX_HIP_TRY(hipMemcpyAsync(c.st, &init, sizeof(init), hipMemcpyHostToDevice, c.stream));
-    LPX_HIP_TRY(hipStreamSynchronize(c.stream));
-
-    if (o->profile) {
-        size_t need = 2 * (size_t)batch;
-        while (c.events->size() < need) {
-            hipEvent_t e;
-            LPX_HIP_TRY(hipEventCreate(&e));
-            c.events->push_back(e);
-        }
+    LoopRun run;
+    int rc = run.begin(c, init, o, budget, cb, user);
+    if (rc) return rc;
+    while (!run.done()) {
+        rc = run.submit(); if (rc) return rc;
+        rc = run.complete(); if (rc) return rc;
     }
-    if (graph) { int rc = build_graph(c, batch); if (rc) return rc; }
-
-    const double t0 = now_ms();
-    if (c.prologue) { int rc = c.prologue(c.stream); if (rc) return rc; local.launches += 1; }
-    int fired = 0;
-    long long enq = 0;
-    int status = LPX_RUNNING;
-    while (status == LPX_RUNNING && enq < budget) {
-        const int iter_before = fired;
-        if (graph) {
-            LPX_HIP_TRY(hipGraphLaunch(*c.gexec, c.stream));
-        } else {
-            for (int i = 0; i < batch; ++i) {
-                int rc = o->profile ? c.enqueue_iter(c.stream, (*c.events)[2 * i], (*c.events)[2 * i + 1])
-                                    : c.enqueue_iter(c.stream, nullptr, nullptr);
-                if (rc) return rc;
-            }
-        }
-        enq += batch;
-        local.launches += (long long)c.launches_per_iter * batch;
-        LPX_HIP_TRY(hipMemcpyAsync(c.hst, c.st, sizeof(DevState), hipMemcpyDeviceToHost, c.stream));
-        LPX_HIP_TRY(hipStreamSynchronize(c.stream));
-        status = c.hst->status;
-        const int done = c.hst->iter;
-        if (o->profile && c.profile_maps) {
-            // the first (done - iter_before) iterations of this batch each ran one full update
-            const int full = done - iter_before;
-            for (int i = 0; i < full && i < batch; ++i) {
-                float ms = 0.f;
-                LPX_HIP_TRY(hipEventElapsedTime(&ms, (*c.events)[2 * i], (*c.events)[2 * i + 1]));
-                local.update_ms_sum += ms;
-                local.update_launches++;
-            }
-        }
-        if (cb && done > fired) {
-            int lo = fired, hi = done < c.trace_cap ? done : c.trace_cap;
-            if (hi > lo) {
-                std::vector<int32_t> tr(2 * (size_t)(hi - lo));
-                LPX_HIP_TRY(hipMemcpy(tr.data(), c.trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
-                for (int k = lo; k < hi; ++k) cb(user, k + 1, tr[2 * (k - lo)], tr[2 * (k - lo) + 1]);
-            }
-        }
-        fired = done;
-    }
-    local.loop_ms = now_ms() - t0;
-    local.pivots = c.hst->iter;
-    local.fdf_pivots = c.hst->fdf_count;
-    local.cleanup_pivots = (init.phase == 0) ? c.hst->primal_count : 0;
-    if (stats) {
-        double h2d = stats->h2d_ms, d2h = stats->d2h_ms;
-        *stats = local; stats->h2d_ms = h2d; stats->d2h_ms = d2h;
-    }
-    if (status == LPX_RUNNING) { set_error("loop budget exhausted while still running"); return LPX_ITER_LIMIT; }
-    return status;
+    return run.finish(stats);
 }
 
 }  // namespace lpx

@@ -265,10 +265,8 @@ int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e
     return 0;
 }
 
-int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budget,
-             lpx_pivot_cb cb, void* user, lpx_stats* stats)
+void make_ctx(lpx_tableau* t, const SelParams& p, LoopCtx& c, DevState& init)
 {
-    LoopCtx c;
     c.stream = t->stream; c.st = t->st; c.hst = t->hst; c.trace = t->trace; c.trace_cap = t->trace_cap;
     c.events = &t->events; c.gexec = &t->gexec; c.g_batch = &t->g_batch; c.g_key = &t->g_key;
     c.key.assign(reinterpret_cast<const char*>(&p), sizeof(p));
@@ -277,9 +275,16 @@ int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budge
         c.prologue = [p](hipStream_t s) -> int { LPX_HIP_TRY(launch_la_init(p, s)); return 0; };
     c.launches_per_iter = 2;
     c.profile_maps = (p.mode != MODE_DUAL);     // phase hops make the mapping ambiguous in dual mode
-    DevState init; std::memset(&init, 0, sizeof(init));
+    std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1;
     init.phase = (p.mode == MODE_DUAL) ? 0 : 2;
+}
+
+int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budget,
+             lpx_pivot_cb cb, void* user, lpx_stats* stats)
+{
+    LoopCtx c; DevState init;
+    make_ctx(t, p, c, init);
     return run_device_loop(c, init, o, budget, cb, user, stats);
 }
 
@@ -374,6 +379,59 @@ static int one_shot(double* T, int R, int C, int32_t* basis, const lpx_run_opts*
     lpx_tableau_destroy(t);
     if (st) *st = local;
     return rc ? rc : status;
+}
+
+int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z)
+{
+    if (!t || nvars < 0) { set_error("lpx_tableau_solution: bad argument"); return LPX_EINVAL; }
+    const int m = t->R - 1;
+    std::vector<double> rhs(t->R);
+    std::vector<int32_t> basis(m > 0 ? m : 1);
+    LPX_HIP_TRY(hipMemcpy2DAsync(rhs.data(), sizeof(double), t->T + (t->C - 1), sizeof(double) * t->ld,
+                                 sizeof(double), t->R, hipMemcpyDeviceToHost, t->stream));
+    if (m > 0) LPX_HIP_TRY(hipMemcpyAsync(basis.data(), t->basis, sizeof(int32_t) * m, hipMemcpyDeviceToHost, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    if (x) {
+        for (int j = 0; j < nvars; ++j) x[j] = 0.0;
+        for (int i = 0; i < m; ++i) if (basis[i] >= 0 && basis[i] < nvars) x[basis[i]] = rhs[i];   // FinalizeReport :135-136
+    }
+    if (z) *z = rhs[m];                                                                           // :138
+    return 0;
+}
+
+int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
+                  const lpx_run_opts* dopts, int* statuses, lpx_stats* stats)
+{
+    if (!ts || !dual || count < 0 || !statuses) { set_error("lpx_multi_run: bad argument"); return LPX_EINVAL; }
+    lpx_run_opts pd, dd;
+    if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
+    if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
+    std::vector<LoopRun> runs(count);
+    std::vector<char> active(count, 0);
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* t = ts[i];
+        if (!t || t->R < 2) { set_error("lpx_multi_run: null or empty tableau"); return LPX_EINVAL; }
+        const lpx_run_opts* o = dual[i] ? dopts : popts;
+        SelParams p = base_params(t, o, dual[i] ? MODE_DUAL : MODE_PRIMAL);
+        LoopCtx c; DevState init;
+        make_ctx(t, p, c, init);
+        long long budget = dual[i] ? (long long)o->fdf_guard + 2LL * o->max_iter + 8 : (long long)o->max_iter + 2;
+        int rc = runs[i].begin(c, init, o, budget, nullptr, nullptr);
+        if (rc) return rc;
+        active[i] = 1;
+    }
+    int remaining = count;
+    while (remaining > 0) {
+        for (int i = 0; i < count; ++i) if (active[i]) { int rc = runs[i].submit(); if (rc) return rc; }
+        for (int i = 0; i < count; ++i) if (active[i]) {
+            int rc = runs[i].complete(); if (rc) return rc;
+            if (runs[i].done()) {
+                statuses[i] = runs[i].finish(stats ? &stats[i] : nullptr);
+                active[i] = 0; --remaining;
+            }
+        }
+    }
+    return 0;
 }
 
 int lpx_primal_tableau(double* T, int R, int C, int32_t* basis, double eps, int max_iter,

@@ -1,0 +1,270 @@
+"""Python face of the reference's plugin boundary (Models/IPLAlgorithm.cs:5-8, Models/LPSolver.cs):
+`LPSolver().Solve(problem, "Primal Simplex")`, `PrimalSimplex().Solve(problem)` ... with the same names
+and error behaviour.  All solving goes through lpx_solve (C ABI) -> C++ host mirror -> HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from enum import IntEnum
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+
+class Sense(IntEnum):       # Models/PrimalSimplex.cs:8
+    Max = 0
+    Min = 1
+
+
+class Rel(IntEnum):         # Models/PrimalSimplex.cs:9
+    LE = 0
+    GE = 1
+    EQ = 2
+
+
+@dataclass
+class Constraint:           # Models/PrimalSimplex.cs:11-18
+    A: Sequence[float]
+    Relation: Rel
+    B: float
+
+
+@dataclass
+class LPProblem:            # Models/PrimalSimplex.cs:20-36
+    ObjectiveSense: Sense = Sense.Max
+    C: Sequence[float] = field(default_factory=list)
+    Constraints: List[Constraint] = field(default_factory=list)
+
+    @property
+    def NumVars(self) -> int:
+        return len(self.C)
+
+    @classmethod
+    def from_arrays(cls, sense, c, A, rel, b) -> "LPProblem":
+        A = np.asarray(A, dtype=np.float64).reshape(len(b), len(c))
+        return cls(Sense(int(sense)), list(map(float, c)),
+                   [Constraint(A[i].tolist(), Rel(int(rel[i])), float(b[i])) for i in range(len(b))])
+
+
+@dataclass
+class SimplexResult:        # Models/PrimalSimplex.cs:38-49 (+ engine extras after VarNames)
+    Report: str
+    Summary: str
+    OptimalValue: float
+    Solution: Optional[np.ndarray]
+    Tableau: Optional[np.ndarray]
+    Basis: Optional[np.ndarray]
+    VarNames: Optional[List[str]]
+    Status: int = 0
+    Trace: Optional[np.ndarray] = None
+    LpSolves: int = 0
+    Nodes: int = 0
+    NodeLog: Optional[np.ndarray] = None
+    NodeZ: Optional[np.ndarray] = None
+    Aux: Optional[list] = None
+    Stats: Optional[dict] = None
+    Extra: Optional[np.ndarray] = None      # revised / knapsack: numbers the reference only prints
+
+
+class SolverException(Exception):
+    """The reference's `throw new Exception(message)`; `.code` is the LPX_E_* of include/lpx.h."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+def _problem_struct(p: LPProblem):
+    n, m = p.NumVars, len(p.Constraints)
+    c = np.ascontiguousarray(p.C, dtype=np.float64)
+    A = np.zeros((max(m, 1), max(n, 1)), dtype=np.float64)
+    rel = np.zeros(max(m, 1), dtype=np.int32)
+    b = np.zeros(max(m, 1), dtype=np.float64)
+    for i, k in enumerate(p.Constraints):
+        if len(k.A) < n:
+            # row.A[j] for j < n (Models/PrimalSimplex.cs:190)
+            raise SolverException(_lib.EINVAL, "Index was outside the bounds of the array.")
+        A[i, :n] = np.asarray(k.A[:n], dtype=np.float64)
+        rel[i] = int(k.Relation)
+        b[i] = float(k.B)
+    st = _lib.Problem(int(p.ObjectiveSense), n, m, c.ctypes.data_as(_lib.dp), A.ctypes.data_as(_lib.dp),
+                      rel.ctypes.data_as(_lib.ip), b.ctypes.data_as(_lib.dp))
+    return st, (c, A, rel, b)
+
+
+def _arr(ptr, n, dtype):
+    if not ptr or n <= 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class LPSolver:             # Models/LPSolver.cs:6-77
+    def __init__(self, **engine):
+        self.engine = engine
+        self.FinalTableau = None
+
+    def Solve(self, problem: LPProblem, algorithm: str,
+              updatePivot: Optional[Callable[[str, Optional[np.ndarray]], None]] = None) -> SimplexResult:
+        L = lib()
+        o = _lib.SolveOpts()
+        L.lpx_default_solve_opts(C.byref(o))
+        keep = []
+        for k, v in self.engine.items():
+            if k == "allreduce_max":
+                fn = v
+
+                def _ar(_u, vals, count, fn=fn):
+                    a = np.ctypeslib.as_array(vals, shape=(count,))
+                    a[:] = fn(a.copy())
+                cb = _lib.ALLREDUCE_CB(_ar)
+                keep.append(cb)
+                o.allreduce_max = cb
+            elif hasattr(o, k):
+                setattr(o, k, v)
+            else:
+                raise TypeError(f"unknown engine option {k!r}")
+        if updatePivot is not None:
+            def _txt(_u, text, hl, R, Cc):
+                mask = None
+                if hl and R > 0:
+                    mask = np.ctypeslib.as_array(hl, shape=(R * Cc,)).astype(bool).reshape(R, Cc)
+                updatePivot(text.decode(errors="replace"), mask)
+            tcb = _lib.TEXT_CB(_txt)
+            keep.append(tcb)
+            o.text_cb = tcb
+        ps, hold = _problem_struct(problem)
+        r = _lib.Result()
+        rc = L.lpx_solve(C.byref(ps), algorithm.encode() if algorithm is not None else b"", C.byref(o), C.byref(r))
+        if rc != 0:
+            raise SolverException(rc, _lib.last_error())
+        try:
+            has = bool(r.has_solution)
+            T = _arr(r.T, r.R * r.C, np.float64).reshape(r.R, r.C) if r.R > 0 else None
+            n = problem.NumVars
+            names = None
+            if has and T is not None:
+                ns = T.shape[1] - 1
+                names = [f"x{j + 1}" for j in range(n)] + [f"c{j + 1}" for j in range(ns - n)]
+            log = _arr(r.node_log, 3 * r.n_log, np.int32).reshape(-1, 3)
+            res = SimplexResult(
+                Report=(r.report or b"").decode(errors="replace"), Summary=(r.summary or b"").decode(errors="replace"),
+                OptimalValue=r.optimal_value,
+                Solution=_arr(r.x, r.n, np.float64) if has else None,
+                Tableau=T if has else None,
+                Basis=_arr(r.basis, max(r.R - 1, 0), np.int32) if has else None,
+                VarNames=names, Status=r.status,
+                Trace=_arr(r.trace, 2 * r.n_pivots, np.int32).reshape(-1, 2),
+                LpSolves=r.lp_solves, Nodes=r.nodes, NodeLog=log, NodeZ=_arr(r.node_z, r.n_log, np.float64),
+                Aux=list(r.aux), Stats=r.stats.as_dict(),
+                Extra=None if has else (T.reshape(-1) if T is not None and T.size else _arr(r.x, r.n, np.float64)))
+            if not has and r.n > 0:
+                res.Extra = _arr(r.x, r.n, np.float64)
+            elif not has and T is not None:
+                res.Extra = T.reshape(-1)
+        finally:
+            L.lpx_result_free(C.byref(r))
+        self.FinalTableau = res.Tableau
+        return res
+
+
+class _Algo:                # ILPAlgorithm, Models/IPLAlgorithm.cs:5-8
+    NAME = ""
+
+    def __init__(self, **engine):
+        self._solver = LPSolver(**engine)
+
+    def Solve(self, problem: LPProblem, updatePivot=None) -> SimplexResult:
+        return self._solver.Solve(problem, self.NAME, updatePivot)
+
+
+class PrimalSimplex(_Algo):             # Models/PrimalSimplex.cs:52
+    NAME = "Primal Simplex"
+
+
+class RevisedPrimalSimplex(_Algo):      # Models/RevisedPrimalSimplex.cs:12
+    NAME = "Revised Primal Simplex"
+
+
+class DualSimplex(_Algo):               # Models/DualSimplex.cs:11
+    NAME = "Dual Simplex"
+
+
+class BranchAndBound(_Algo):            # Models/Branch&Bound.cs:20
+    NAME = "Branch and Bound"
+
+
+class BranchAndBoundKnapsack(_Algo):    # Models/BranchAndBoundKnapsack.cs:12
+    NAME = "Branch and Bound Knapsack"
+
+
+def ParseFromText(text: str) -> LPProblem:
+    """LPParser.ParseFromText (Models/LPParser.cs:9-79). Ragged rows are kept ragged."""
+    L = lib()
+    p = _lib.Parsed()
+    rc = L.lpx_parse_text(text.encode(), C.byref(p))
+    if rc != 0:
+        raise SolverException(rc, _lib.last_error())
+    try:
+        c = _arr(p.c, p.n, np.float64)
+        A = _arr(p.A, p.m * p.n, np.float64).reshape(p.m, p.n)
+        rel = _arr(p.rel, p.m, np.int32)
+        b = _arr(p.b, p.m, np.float64)
+        prob = LPProblem.from_arrays(p.sense, c, A, rel, b)
+        prob.ragged = bool(p.ragged)
+    finally:
+        L.lpx_parsed_free(C.byref(p))
+    return prob
+
+
+def format_number(v: float) -> str:
+    buf = C.create_string_buffer(64)
+    lib().lpx_format_number(float(v), buf, 64)
+    return buf.value.decode()
+
+
+class DeviceKnapsack:
+    """Batched ComputeRelaxation (Models/BranchAndBoundKnapsack.cs:431-491) on the GPU."""
+
+    def __init__(self, profit, weight, cap: float):
+        self.profit = np.ascontiguousarray(profit, dtype=np.float64)
+        self.weight = np.ascontiguousarray(weight, dtype=np.float64)
+        self.n = len(self.profit)
+        self._h = C.c_void_p()
+        _lib.check(lib().lpx_knapsack_create(self.profit.ctypes.data_as(_lib.dp), self.weight.ctypes.data_as(_lib.dp),
+                                             self.n, float(cap), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().lpx_knapsack_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def order(self) -> np.ndarray:
+        o = np.zeros(self.n, np.int32)
+        _lib.check(lib().lpx_knapsack_order(self._h, o.ctypes.data_as(_lib.ip)))
+        return o
+
+    def relax_batch(self, nodes):
+        """nodes: list of dict {item_index: 0/1}. Returns (profit, weight, frac_sorted_idx, frac_value)."""
+        off = [0]
+        fidx, fval = [], []
+        for nd in nodes:
+            for i in sorted(nd):
+                fidx.append(i)
+                fval.append(nd[i])
+            off.append(len(fidx))
+        off = np.asarray(off, np.int32)
+        fi = np.asarray(fidx if fidx else [0], np.int32)
+        fv = np.asarray(fval if fval else [0], np.int8)
+        k = len(nodes)
+        p = np.zeros(k); w = np.zeros(k); fr = np.zeros(k, np.int32); fx = np.zeros(k)
+        _lib.check(lib().lpx_knapsack_relax_batch(self._h, k, off.ctypes.data_as(_lib.ip), fi.ctypes.data_as(_lib.ip),
+                                                  fv.ctypes.data_as(C.POINTER(C.c_int8)), p.ctypes.data_as(_lib.dp),
+                                                  w.ctypes.data_as(_lib.dp), fr.ctypes.data_as(_lib.ip),
+                                                  fx.ctypes.data_as(_lib.dp)))
+        return p, w, fr, fx

@@ -54,4 +54,4 @@ def test_product_never_references_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
-                assert "oracle" not in txt.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"
+                assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
