@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the lpx simplex hot path on MI355X.
+"""bench.py -- headline benchmark of the lpx simplex / branch-and-bound hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one complete device-resident solve of BASELINE.json's config 2 (dense random LP
-m=1024, n=2048, primal tableau simplex, seed 20251003) starting from the slack basis: the
-tableau is restored from a pristine HBM snapshot (D2D, inside the timed region) and the
-select/update loop runs to OPTIMAL.  `value` = pivots completed by all ranks / max-over-ranks
-wall time.  A single LP does not shard (DESIGN.md "Multi-GPU"): with --gpus N every rank
-solves its own replica of the workload on its own GPU ("replicas only", weak scaling).
-
-Extra objects on the same JSON line:
-  roofline          rank-1 update kernel on THIS workload: algorithmic bytes (16*R*C per pivot)
-                    / average kernel duration measured with HIP events around each launch on
-                    the library's stream (profile pass over the same solve, rank 0).
-  roofline_headline the same kernel on the north-star shape, raw tableau 4096x8192 FP64
-                    (268 MB > 256 MiB Infinity Cache, a true HBM stream), >=200 timed pivots.
-  cpu_baseline      the CPU oracle (C restatement of the reference's scalar loops, 1 core) on
-                    a bounded sample of the same LP (rank 0, N=1 only).
+value (pivots/s)   A "step" is one complete device-resident solve of BASELINE.json's config 2 (dense
+                   random LP m=1024 n=2048, primal tableau simplex, seed 20251003) from the slack basis:
+                   the tableau is restored from a pristine HBM snapshot (D2D, inside the timed region)
+                   and the select/update loop runs to OPTIMAL.  value = pivots of all ranks / max wall.
+                   A single LP does not shard (DESIGN.md "Multi-GPU"): with N ranks each rank solves its
+                   own replica on its own GPU ("replicas only", weak scaling).
+Extra objects on the same JSON line (rank 0 unless stated):
+  roofline           lpx_update (rank-1 pivot update) on THIS workload: algorithmic bytes 16*R*C per
+                     launch / average kernel duration from HIP events bound to each dispatch
+                     (hipExtLaunchKernelGGL start/stop events on the library's stream), profile pass
+                     over the same solve.
+  roofline_headline  the same kernel on the north-star shape, raw 4096x8192 f64 tableau (268 MB, a true
+                     HBM stream), 200 timed pivots after 20 warm-ups; plus whole-loop pivots/s there.
+  cpu_baseline       CPU oracle (C port of the reference's scalar loops, 1 core) on the same LP.
+  revised            config 3: revised simplex m=4096 n=8192, iterations/s over a bounded run.
+  bnb                config 4: 0/1 IP n=512 m=256 (+512 bound rows), repaired mode, node queue SHARDED
+                     over all ranks (level-synchronous, one all-reduce(max) per level over RCCL);
+                     nodes/s = LP relaxations solved by all ranks / max wall.  All ranks take part.
+  knapsack           config 5: 100k-item 0/1 knapsack, best-first B&B with batched GPU bounds, sharded
+                     subtrees over all ranks; nodes/s = popped nodes of all ranks / max wall.
 """
 import argparse
 import json
@@ -41,9 +47,13 @@ def main():
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline/cpu_baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline value")
     ap.add_argument("--headline-pivots", type=int, default=200)
     ap.add_argument("--cpu-sample-pivots", type=int, default=10000)
+    ap.add_argument("--bnb-nodes", type=int, default=48, help="node budget per rank (config 4 leg)")
+    ap.add_argument("--bnb-concurrent", type=int, default=8)
+    ap.add_argument("--knap-nodes", type=int, default=40000, help="pop budget per rank (config 5 leg)")
+    ap.add_argument("--revised-iters", type=int, default=300)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,7 +77,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- workload: config 2 -------------------------------------------------------------------
+    def allreduce_max(vals):
+        """X1: the incumbent exchange -- one RCCL all-reduce(max) over xGMI per level / round."""
+        if world == 1:
+            return vals
+        t = torch.from_numpy(np.ascontiguousarray(vals)).cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    def reduce_sum_max(count, seconds):
+        if world == 1:
+            return float(count), float(seconds)
+        a = torch.tensor([float(count)], dtype=torch.float64, device="cuda")
+        b = torch.tensor([float(seconds)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        return float(a.item()), float(b.item())
+
+    # ---- headline workload: config 2 ------------------------------------------------------------
     m, n = args.m, args.n
     c, A, b = synth.dense_lp(m, n, seed=synth.SEED + rank)   # one replica per rank, own seed
     T, basis = synth.primal_tableau_from(c, A, b)
@@ -94,16 +121,7 @@ def main():
         loop_ms += st["loop_ms"]
     barrier()
     dt_s = time.perf_counter() - t0
-
-    tot = torch.tensor([float(pivots), dt_s], dtype=torch.float64, device="cuda")
-    if world > 1:
-        t_max = tot[1:2].clone()
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        p_sum = tot[0:1].clone()
-        dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
-        total_pivots, wall = float(p_sum.item()), float(t_max.item())
-    else:
-        total_pivots, wall = float(pivots), dt_s
+    total_pivots, wall = reduce_sum_max(pivots, dt_s)
 
     out = {
         "metric": METRIC,
@@ -129,8 +147,43 @@ def main():
         },
     }
 
+    if not args.no_extras:
+        # ---- config 4: sharded branch and bound (all ranks) -------------------------------------------
+        cb, Ab, relb, bb = synth.binary_ip(512, 256)
+        pb = L.LPProblem.from_arrays(0, cb, Ab, relb, bb)
+        bnb = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=args.bnb_concurrent,
+                               max_nodes=args.bnb_nodes, rank=rank, world=world, allreduce_max=allreduce_max)
+        barrier()
+        t1 = time.perf_counter()
+        rb = bnb.Solve(pb)
+        barrier()
+        tb = time.perf_counter() - t1
+        lp_total, tb_max = reduce_sum_max(rb.LpSolves, tb)
+        piv_total, _ = reduce_sum_max(rb.Stats["pivots"], tb)
+        out["bnb"] = {"workload": "random 0/1 IP n=512 m=256 + 512 rows x_j<=1 (config 4), repaired mode, "
+                                  "level-synchronous sharded node queue, node budget per rank "
+                                  f"{args.bnb_nodes}, {args.bnb_concurrent} node LPs in flight per GPU",
+                      "nodes_per_s": lp_total / tb_max, "lp_relaxations": lp_total, "pivots": piv_total,
+                      "wall_s": tb_max, "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
+                      "collective": "1 all-reduce(max) of {incumbent, have_work} per level (RCCL)" if world > 1 else "none (1 rank)"}
+        # ---- config 5: sharded knapsack (all ranks) ---------------------------------------------------
+        pk, wk, capk = synth.knapsack(100_000)
+        kp = L.LPProblem(L.Sense.Max, pk.tolist(), [L.Constraint(wk.tolist(), L.Rel.LE, capk)])
+        kn = L.BranchAndBoundKnapsack(max_nodes=args.knap_nodes, concurrent_nodes=512, rank=rank, world=world,
+                                      allreduce_max=allreduce_max)
+        barrier()
+        t1 = time.perf_counter()
+        rk = kn.Solve(kp)
+        barrier()
+        tk = time.perf_counter() - t1
+        pop_total, tk_max = reduce_sum_max(rk.Nodes, tk)
+        rel_total, _ = reduce_sum_max(rk.Aux[0], tk)
+        out["knapsack"] = {"workload": f"0/1 knapsack n=100000 (config 5), best-first B&B, pop budget per rank {args.knap_nodes}",
+                           "nodes_per_s": pop_total / tk_max, "popped": pop_total, "relaxations": rel_total,
+                           "relaxations_per_s": rel_total / tk_max, "wall_s": tk_max, "incumbent": rk.OptimalValue}
+
     if rank == 0 and not args.no_extras:
-        # ---- roofline of the rank-1 update kernel on this workload (HIP events, profile pass) ----
+        # ---- roofline of the rank-1 update kernel on this workload (profile pass) ---------------------
         popts = L.default_opts(False, batch=args.batch, profile=1)
         dt.restore()
         status, pst = dt.primal_run(popts)
@@ -141,8 +194,9 @@ def main():
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "avg_kernel_us": 1e3 * k_ms, "launches": pst["update_launches"],
                            "algorithmic_bytes_per_launch": alg,
-                           "note": "25 MB tableau: resident in the 256 MiB Infinity Cache, not an HBM stream"}
-        # ---- headline shape: raw 4096x8192 tableau, forced pivots -----------------------------------
+                           "note": "25 MB tableau: resident in the 256 MiB Infinity Cache, not an HBM stream; "
+                                   "see roofline_headline for the HBM-streaming shape"}
+        # ---- headline shape: raw 4096x8192 tableau, forced pivots -------------------------------------
         HR, HC = 4096, 8192
         Th = synth.raw_tableau(HR, HC)
         hd = L.DeviceTableau.from_host(Th)
@@ -152,31 +206,52 @@ def main():
         hk_ms = hst["update_ms_sum"] / max(hst["update_launches"], 1)
         halg = 16.0 * HR * HC
         hach = halg / (hk_ms * 1e-3) / 1e9
-        # whole-loop pivots/s on the headline shape (graph replay, select + update)
         hd.upload(Th)
-        t1 = time.perf_counter()
         _, hst2 = hd.forced_pivots(rows[20:], cols[20:], 0.1, batch=100)
-        hwall = time.perf_counter() - t1
         out["roofline_headline"] = {"kernel": "lpx_update", "shape": [HR, HC], "bound": "hbm",
                                     "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": hach / HBM_PEAK_GBS, "traffic": None,
                                     "avg_kernel_us": 1e3 * hk_ms, "launches": hst["update_launches"],
                                     "algorithmic_bytes_per_launch": halg,
-                                    "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3),
-                                    "host_wall_s": hwall}
+                                    "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}
         hd.close()
-        # ---- CPU baseline: oracle (C port of the reference loops), 1 core, bounded sample ----------
+        # ---- config 3: revised simplex m=4096 n=8192 -----------------------------------------------------
+        c3, A3, b3 = synth.dense_lp(4096, 8192)
+        rv = L.DeviceRevised(A3, -c3, b3)
+        rv.run(max_iter=20, batch=20)
+        rv.close()
+        rv = L.DeviceRevised(A3, -c3, b3)
+        st3, s3 = rv.run(max_iter=args.revised_iters, batch=50)
+        out["revised"] = {"workload": "dense random LP m=4096 n=8192, revised simplex (config 3), "
+                                      f"first {s3['pivots']} iterations from the slack basis",
+                          "iterations_per_s": s3["pivots"] / (s3["loop_ms"] * 1e-3),
+                          "us_per_iteration": 1e3 * s3["loop_ms"] / max(s3["pivots"], 1),
+                          "unfused_reference_bytes_per_iteration": 8.0 * (5 * 4096 ** 2 + 4096 * 8192),
+                          "engine_bytes_per_iteration": 8.0 * (4096 * 8192 + 4096 ** 2) + 16.0 * 4097 * 4097}
+        rv.close()
+        # ---- CPU baseline: oracle (C port of the reference loops), 1 core -------------------------------
         if world == 1:
             from oracle import oracle as O
             Tc, bc = T.copy(), basis.copy()
-            k = args.cpu_sample_pivots
             t2 = time.perf_counter()
-            st_c, tr_c = O.primal_tableau(Tc, bc, max_iter=k)
+            st_c, tr_c = O.primal_tableau(Tc, bc, max_iter=args.cpu_sample_pivots)
             cpu_s = time.perf_counter() - t2
             out["cpu_baseline"] = {"value": len(tr_c) / cpu_s, "unit": "pivots/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
+                                   "sample": f"all {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
                                              f"(gcc -O2 -ffp-contract=off, scalar), {cpu_s:.1f} s"}
+            # bounded CPU samples of the other legs, for the record
+            t2 = time.perf_counter()
+            rk_c = O.knapsack_solve(O.Problem(O.MAX, pk, wk.reshape(1, -1), [O.LE], [capk]), max_nodes=4000)
+            ck = time.perf_counter() - t2
+            out["cpu_baseline"]["knapsack_nodes_per_s"] = rk_c.nodes_popped / ck
+            out["cpu_baseline"]["knapsack_sample"] = f"first {rk_c.nodes_popped} pops of config 5, oracle/knapsack.c, {ck:.1f} s"
+            t2 = time.perf_counter()
+            rb_c = O.bnb_solve(O.Problem(O.MAX, cb, Ab, relb.astype(np.int32), bb), 1, max_nodes=5)
+            cbn = time.perf_counter() - t2
+            out["cpu_baseline"]["bnb_nodes_per_s"] = rb_c.lp_solves / cbn
+            out["cpu_baseline"]["bnb_sample"] = f"first {rb_c.lp_solves} LP relaxations of config 4 (repaired, DFS), oracle/bnb.c, {cbn:.1f} s"
     dt.close()
+    barrier()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

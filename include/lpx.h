@@ -210,6 +210,18 @@ typedef struct lpx_solve_opts {
     /* Action<string,bool[,]>: text + optional R x C highlight mask (NULL = none) */
     void (*text_cb)(void* user, const char* text, const uint8_t* highlight, int R, int C);
     void* text_user;
+    /* TEST SEAMS -- NULL in every product path.  They let the CPU-only test-suite drive the sharded
+     * host logic (frontier partition, per-level all-reduce, termination) under torch.distributed/gloo
+     * with world_size 2 on a box without a GPU, by standing in for the device loops:
+     *   test_node_lp      replaces lpx_multi_run + lpx_tableau_solution for ONE prepared node tableau
+     *                     (T is R x C row-major, modified in place; returns the LPX_* status)
+     *   test_knap_relax   replaces lpx_knapsack_relax_batch (same argument meaning) */
+    int (*test_node_lp)(void* user, double* T, int R, int C, int32_t* basis, int dual, int repaired,
+                        int max_iter, int nvars, double* x, double* z, int64_t* pivots);
+    int (*test_knap_relax)(void* user, int count, const int32_t* off, const int32_t* fix_idx,
+                           const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                           double* frac_val);
+    void* test_user;
 } lpx_solve_opts;
 
 typedef struct lpx_result {                        /* SimplexResult, Models/PrimalSimplex.cs:38-49 */

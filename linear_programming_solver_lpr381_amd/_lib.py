@@ -45,6 +45,12 @@ ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int)
 
 
+# test seams (include/lpx.h): only the CPU test-suite sets these
+TEST_NODE_LP = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,
+                           C.POINTER(C.c_int64))
+TEST_KNAP_RELAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp)
+
+
 class Problem(C.Structure):
     _fields_ = [("sense", C.c_int), ("n", C.c_int), ("m", C.c_int), ("c", dp), ("A", dp), ("rel", ip), ("b", dp)]
 
@@ -54,7 +60,8 @@ class SolveOpts(C.Structure):
                 ("dual_flags", C.c_int), ("bnb_mode", C.c_int), ("bnb_search", C.c_int),
                 ("concurrent_nodes", C.c_int), ("rank", C.c_int), ("world", C.c_int),
                 ("max_nodes", C.c_int64), ("allreduce_max", ALLREDUCE_CB), ("allreduce_user", C.c_void_p),
-                ("text_cb", TEXT_CB), ("text_user", C.c_void_p)]
+                ("text_cb", TEXT_CB), ("text_user", C.c_void_p),
+                ("test_node_lp", TEST_NODE_LP), ("test_knap_relax", TEST_KNAP_RELAX), ("test_user", C.c_void_p)]
 
 
 class Result(C.Structure):

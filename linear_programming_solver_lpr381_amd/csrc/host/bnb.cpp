@@ -156,6 +156,20 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     lpx_run_opts po, dopt; lpx_default_opts(&po, 0); lpx_default_opts(&dopt, 1);
     po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
+    if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
+        for (NodeLP* lp : group) {
+            c.out->LpSolves++;
+            if (lp->error || lp->R < 2) { lp->error = true; continue; }
+            lp->x.assign(nvars, 0.0);
+            int64_t piv = 0;
+            int st = c.opt.test_node_lp(lp->T.data(), lp->R, lp->C, lp->basis.data(), lp->dual ? 1 : 0, c.opt.bnb_mode,
+                                        c.opt.max_iter, nvars, lp->x.data(), &lp->z, &piv);
+            c.out->Stats.pivots += piv; lp->pivots = piv; lp->status = st;
+            if (st < 0 || st == LPX_ITER_LIMIT) lp->error = true;
+            else lp->has_solution = !(lp->dual && c.opt.bnb_mode == 0);
+        }
+        return;
+    }
     const size_t width = (size_t)std::max(1, c.opt.concurrent_nodes);
     for (size_t a = 0; a < group.size(); a += width) {
         const size_t b = std::min(group.size(), a + width);
@@ -327,6 +341,14 @@ SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot update
     SimplexResult rootRes;
     out.LpSolves = 1;
     try {
+        if (opt.test_node_lp) {             // test seam: no device, no root tableau in the result
+            NodeLP lp; prepare(c, problem, lp);
+            std::vector<NodeLP*> g{&lp};
+            out.LpSolves = 0;
+            solve_group(c, g, problem.NumVars());
+            if (lp.error) throw LpxException(LPX_EINVAL, "root relaxation failed");
+            rootRes.HasSolution = lp.has_solution; rootRes.Solution = lp.x; rootRes.OptimalValue = lp.z;
+        } else
         rootRes = solver.Solve(problem, rootAlgo, nullptr);                               // :57
     } catch (const LpxException& ex) {
         if (ex.code == LPX_EDEVICE || ex.code == LPX_ENOMEM) throw;

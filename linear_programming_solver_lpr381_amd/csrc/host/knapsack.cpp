@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
 
 namespace lpx { namespace host {
@@ -68,6 +69,7 @@ struct Search {
     double best = -INFINITY; std::vector<int32_t> bestX; bool has_best = false;
     int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0;
     int spec = 64;
+    std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
 
     // evaluates `jobs` = (node, fixed item, value) in one launch
     struct Job { KNode* node; int item; int v; Relax* out; };
@@ -86,7 +88,8 @@ struct Search {
         }
         std::vector<double> p(jobs.size()), w(jobs.size()), fv(jobs.size()); std::vector<int32_t> fr(jobs.size());
         if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
-        int rc = lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
+        int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                            : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         ++launches;
         for (size_t j = 0; j < jobs.size(); ++j) {
@@ -202,12 +205,24 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     Search S;
     S.n = n; S.cap = cons.B; S.profit = problem.C; S.weight.assign(cons.A.begin(), cons.A.begin() + n);
     lpx_knapsack* kh = nullptr;
-    int rc = lpx_knapsack_create(S.profit.data(), S.weight.data(), n, S.cap, &kh);
-    if (rc) throw LpxException(rc, "liblpx: " + last_error());
+    S.test_relax = opt.test_knap_relax;
+    S.order.resize(n);
+    if (!S.test_relax) {
+        int rc = lpx_knapsack_create(S.profit.data(), S.weight.data(), n, S.cap, &kh);
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        lpx_knapsack_order(kh, S.order.data());
+    } else {
+        // test seam: same ratio order as lpx_knapsack_create (Models/BranchAndBoundKnapsack.cs:19,75-79)
+        std::vector<double> ratio(n);
+        for (int i = 0; i < n; ++i) ratio[i] = S.weight[i] > 0 ? S.profit[i] / S.weight[i] : INFINITY;
+        for (int i = 0; i < n; ++i) S.order[i] = i;
+        std::stable_sort(S.order.begin(), S.order.end(), [&](int a, int b) {
+            if (ratio[a] != ratio[b]) return ratio[a] > ratio[b];
+            return S.profit[a] > S.profit[b];
+        });
+    }
     struct Guard { lpx_knapsack* k; ~Guard() { lpx_knapsack_destroy(k); } } guard{kh};
     S.k = kh;
-    S.order.resize(n);
-    lpx_knapsack_order(kh, S.order.data());
     S.bestX.assign(n, 0);
     S.spec = opt.concurrent_nodes > 1 ? opt.concurrent_nodes : 64;
 

@@ -80,6 +80,11 @@ struct EngineOptions {
     // ranks in place (RCCL all-reduce in production, identity for one process).
     std::function<void(double* vals, int count)> allreduce_max;
     int max_iter = 10000;
+    // test seams (see include/lpx.h); never set by product code
+    std::function<int(double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
+                      double* x, double* z, int64_t* pivots)> test_node_lp;
+    std::function<int(int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,
+                      double* weight, int32_t* frac, double* fracval)> test_knap_relax;
 };
 
 enum { LPX_DUAL_FIX_D1 = 1, LPX_DUAL_FIX_D2 = 2, LPX_DUAL_SOUND = 4, LPX_DUAL_REPAIRED = 7 };

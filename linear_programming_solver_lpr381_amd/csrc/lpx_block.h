@@ -7,10 +7,10 @@
 
 namespace lpx {
 
-static constexpr int SEL_NT = 1024;          // lanes of the select workgroup
+static constexpr int SEL_NT = 1024;          // lanes of the single-workgroup select kernels
 static constexpr int SEL_NW = SEL_NT / 64;   // waves
-static constexpr int LIST_CAP = 2048;        // prefix-minimum records kept in LDS
-static constexpr int SEL_LDS_DOUBLES = 16384;// 128 KiB of dynamic LDS for ratios
+static constexpr int MB_NT = 256;            // lanes of one workgroup of the multi-workgroup select
+static constexpr int MB_MAXB = 64;           // at most this many workgroups (partials fit one wave)
 
 // ------------------------------------------------------------------------------------------------
 // workgroup primitives (wave64)
@@ -24,34 +24,77 @@ __device__ __forceinline__ MinIdx mi_pick(MinIdx a, MinIdx b)
     return a;
 }
 
-__device__ __forceinline__ MinIdx wave_min_idx(MinIdx x)
+// DPP cross-lane moves (row_shr within 16-lane rows, row_bcast15/31 across rows): a few cycles each,
+// where __shfl lowers to ds_bpermute_b32 through the LDS crossbar (~100+ cycles on a dependent chain).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double identity, double x)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        MinIdx y;
-        y.v = __shfl_xor(x.v, d, 64);
-        y.i = __shfl_xor(x.i, d, 64);
-        x = mi_pick(x, y);
-    }
-    return x;
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int identity, int x)
+{
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ double fmin_nn(double a, double b) { return b < a ? b : a; }
+
+// wave-wide minimum of a double, returned in every lane (inclusive scan to lane 63 + readlane)
+__device__ __forceinline__ double wave_min_f64(double x)
+{
+    const double inf = __builtin_inf();
+    x = fmin_nn(x, dpp_f64<0x111, 0xf>(inf, x));     // row_shr:1
+    x = fmin_nn(x, dpp_f64<0x112, 0xf>(inf, x));     // row_shr:2
+    x = fmin_nn(x, dpp_f64<0x114, 0xf>(inf, x));     // row_shr:4
+    x = fmin_nn(x, dpp_f64<0x118, 0xf>(inf, x));     // row_shr:8
+    x = fmin_nn(x, dpp_f64<0x142, 0xa>(inf, x));     // row_bcast:15 into rows 1 and 3
+    x = fmin_nn(x, dpp_f64<0x143, 0xc>(inf, x));     // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+    const int id = INT_MAX;
+    x = min(x, dpp_i32<0x111, 0xf>(id, x));
+    x = min(x, dpp_i32<0x112, 0xf>(id, x));
+    x = min(x, dpp_i32<0x114, 0xf>(id, x));
+    x = min(x, dpp_i32<0x118, 0xf>(id, x));
+    x = min(x, dpp_i32<0x142, 0xa>(id, x));
+    x = min(x, dpp_i32<0x143, 0xc>(id, x));
+    return __builtin_amdgcn_readlane(x, 63);
 }
 
-// All SEL_NT lanes call this. Returns the block-wide winner in every lane.
+// (value, index) minimum with lowest index on equal values, in every lane.  Values are never NaN here
+// (they only ever enter a MinIdx through a `<` comparison).
+__device__ __forceinline__ MinIdx wave_min_idx(MinIdx x)
+{
+    MinIdx r;
+    r.v = wave_min_f64(x.v);
+    r.i = wave_min_i32(x.v == r.v ? x.i : INT_MAX);
+    return r;
+}
+
+// All NT lanes call this. Returns the block-wide winner in every lane.
+template <int NT = SEL_NT>
 __device__ inline MinIdx block_min_idx(MinIdx x, double* s_v, int* s_i)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     x = wave_min_idx(x);
     __syncthreads();                     // protect s_v/s_i reuse
     if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
     __syncthreads();
     MinIdx y;
-    y.v = s_v[lane & (SEL_NW - 1)];
-    y.i = s_i[lane & (SEL_NW - 1)];
+    y.v = s_v[lane & (NW - 1)];
+    y.i = s_i[lane & (NW - 1)];
     y = wave_min_idx(y);
     return y;
 }
 
 // exclusive prefix-minimum over lanes in thread order; identity = +inf
+template <int NT = SEL_NT>
 __device__ inline double block_excl_scan_min(double x, double* s_v)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -72,8 +115,10 @@ __device__ inline double block_excl_scan_min(double x, double* s_v)
 }
 
 // exclusive prefix-sum over lanes in thread order; *total receives the block sum
+template <int NT = SEL_NT>
 __device__ inline int block_excl_scan_sum(int x, int* s_i, int* total)
 {
+    constexpr int NW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = x;
 #pragma unroll
@@ -85,85 +130,136 @@ __device__ inline int block_excl_scan_sum(int x, int* s_i, int* total)
     if (lane == 63) s_i[wave] = inc;
     __syncthreads();
     int pre = 0, tot = 0;
-    for (int w = 0; w < SEL_NW; ++w) { int y = s_i[w]; if (w < wave) pre += y; tot += y; }
+    for (int w = 0; w < NW; ++w) { int y = s_i[w]; if (w < wave) pre += y; tot += y; }
     *total = tot;
     return pre + inc - x;
 }
 
 // ------------------------------------------------------------------------------------------------
 // The reference's ratio scans are NOT argmins: `if (ratio < best - tol) { best = ratio; row = i; }`
-// (Models/PrimalSimplex.cs:229-241, Models/DualSimplex.cs:79-91,:214-222) is a sequential hysteresis
-// chain.  Exact parallel form: a candidate can only be accepted if it is a strict prefix-minimum
-// record (accepted => ratio < fl(best - tol) <= min of all earlier ratios, because best never
-// exceeds fl(prefix_min + tol) ... see DESIGN.md "hysteresis scan").  So: ratios -> LDS, exclusive
-// prefix-min scan, compact the records in order, and one lane replays the chain over the (few)
-// records.  Falls back to a plain sequential replay when the record list overflows.
-// ratio(k) must return +inf for ineligible entries.
+// (Models/PrimalSimplex.cs:229-241, Models/DualSimplex.cs:79-91,:214-222, RevisedPrimalSimplex.cs:101-111)
+// is a sequential hysteresis chain whose winner depends on the order of the rows.
+//
+// Exact wave-parallel form, no LDS and no barrier: the accepted rows are found one after the other as
+// "the first position after the last accepted one whose ratio is below best - tol".  One wave keeps a
+// segment of 64 x WH_PER ratios in registers (lane-strided, so the loads are fully coalesced); the
+// search for the next accepted position is WH_PER wave-uniform ballots, and the number of rounds is the
+// number of accepted rows (about ln L for random data, 1-2 for the degenerate ties of 0/1 programs).
+// Segments are processed in order with (best, position) carried across.  `src` supplies den(k), num(k)
+// -- plain loads, issued unconditionally and up front so that no load waits behind the eligibility
+// test of another -- and value(den, num), which returns +inf for ineligible entries.
 // ------------------------------------------------------------------------------------------------
-template <class RatioFn>
-__device__ int block_hysteresis_argmin(int L, double tol, RatioFn ratio, double* rbuf,
-                                       int* s_list, double* s_v, int* s_i, int* s_out)
+static constexpr int WH_PER = 16;
+
+template <class Src>
+__device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src)
 {
-    const int t = threadIdx.x;
-    const int per = (L + SEL_NT - 1) / SEL_NT;
-    const int lo = t * per;
-    const int hi = (lo + per < L) ? lo + per : L;
-    double lmin = __builtin_inf();
-    for (int k = lo; k < hi; ++k) {
-        double r = ratio(k);
-        rbuf[k] = r;
-        if (r < lmin) lmin = r;
-    }
-    const double pre = block_excl_scan_min(lmin, s_v);
-    int cnt = 0;
-    double run = pre;
-    for (int k = lo; k < hi; ++k) {
-        double r = rbuf[k];
-        if (r < run) { ++cnt; run = r; }
-    }
-    int total;
-    int pos = block_excl_scan_sum(cnt, s_i, &total);
-    if (total <= LIST_CAP) {
-        run = pre;
-        for (int k = lo; k < hi; ++k) {
-            double r = rbuf[k];
-            if (r < run) { s_list[pos++] = k; run = r; }
+    const int lane = threadIdx.x & 63;
+    double best = __builtin_inf();
+    int win = -1;
+    for (int seg = 0; seg < L; seg += 64 * WH_PER) {
+        double den[WH_PER], num[WH_PER], rt[WH_PER];
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) {
+            // clamped index instead of a guard: a guarded load becomes its own exec-masked branch with
+            // its own s_waitcnt and the 32 loads serialise (measured: 14.8k cycles -> see DESIGN.md)
+            const int k = min(seg + u * 64 + lane, L - 1);
+            den[u] = src.den(k); num[u] = src.num(k);
+        }
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) {
+            const int k = seg + u * 64 + lane;
+            rt[u] = (k < L) ? src.value(den[u], num[u]) : __builtin_inf();
+        }
+        // Fast path.  Let rmin be the segment minimum and i* its first position.  No row of the segment
+        // can be accepted unless rmin < fl(best - tol) (every ratio is >= rmin).  If that holds and every
+        // OTHER row j has fl(r_j - tol) > rmin, then i* is accepted when the scan reaches it (whatever
+        // was accepted before is either the carried best or some r_j, both leave rmin below the
+        // threshold) and nothing after it can be (needs r < fl(rmin - tol) <= rmin).  So the chain ends
+        // this segment at (rmin, i*) -- no replay needed.  Exact ties and near-ties fall through.
+        MinIdx lm; lm.v = __builtin_inf(); lm.i = INT_MAX;
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) if (rt[u] < lm.v) { lm.v = rt[u]; lm.i = u * 64 + lane; }
+        lm = wave_min_idx(lm);
+        if (!(lm.v < best - tol)) continue;              // nothing in this segment beats the carried best
+        int inband = 0;
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) inband += ((rt[u] - tol) <= lm.v) ? 1 : 0;
+        if (__ballot(inband >= 2) == 0ull && __popcll(__ballot(inband == 1)) == 1) {
+            best = lm.v; win = seg + lm.i;
+            continue;
+        }
+        int pos = -1;                                   // last accepted position inside this segment
+        for (;;) {
+            const double thr = best - tol;
+            int found = -1;
+#pragma unroll
+            for (int u = 0; u < WH_PER; ++u) {
+                if (found < 0) {
+                    unsigned long long mk = __ballot(rt[u] < thr);
+                    const int base = u * 64;
+                    if (base + 63 <= pos) mk = 0ull;
+                    else if (base <= pos) mk &= ~((2ull << (pos - base)) - 1ull);
+                    if (mk) found = base + __ffsll((long long)mk) - 1;
+                }
+            }
+            if (found < 0) break;
+            double v = 0.0;
+#pragma unroll
+            for (int u = 0; u < WH_PER; ++u) if (u == (found >> 6)) v = rt[u];
+            best = __shfl(v, found & 63, 64);
+            win = seg + found;
+            pos = found;
         }
     }
-    __syncthreads();
-    if (t == 0) {
-        double best = __builtin_inf();
-        int win = -1;
-        if (total <= LIST_CAP) {
-            for (int e = 0; e < total; ++e) {
-                int k = s_list[e];
-                double r = rbuf[k];
-                if (r < best - tol) { best = r; win = k; }
-            }
-        } else {
-            for (int k = 0; k < L; ++k) {
-                double r = rbuf[k];
-                if (r < best - tol) { best = r; win = k; }
-            }
-        }
-        *s_out = win;
-    }
-    __syncthreads();
-    return *s_out;
+    return win;
 }
+
+// wave 0 runs the scan, everybody gets the answer (single-workgroup select kernels)
+template <class Src>
+__device__ __forceinline__ int block_hysteresis_argmin(int L, double tol, const Src& src, int* s_out)
+{
+    if ((threadIdx.x >> 6) == 0) {
+        const int w = wave_hysteresis_argmin(L, tol, src);
+        if (threadIdx.x == 0) *s_out = w;
+    }
+    __syncthreads();
+    const int r = *s_out;
+    __syncthreads();                                    // s_out may be reused by the next scan
+    return r;
+}
+
+// ratio sources ------------------------------------------------------------------------------------
+// rows: den = col[i*cs], num = rhs[i*rs], eligible den > eps, ratio = num/den
+//       (ChooseLeaving, Models/PrimalSimplex.cs:229-241; revised ratio test, RevisedPrimalSimplex.cs:101-111)
+struct RowRatio {
+    const double* col; size_t cs; const double* rhs; size_t rs; double eps;
+    __device__ __forceinline__ double den(int i) const { return col[(size_t)i * cs]; }
+    __device__ __forceinline__ double num(int i) const { return rhs[(size_t)i * rs]; }
+    __device__ __forceinline__ double value(double a, double b) const { return a > eps ? b / a : __builtin_inf(); }
+};
+// columns of the dual loop: den = T[r,j], num = T[m,j], eligible den < -eps, ratio = num/(-den)
+//       (Models/DualSimplex.cs:79-91)
+struct DualColRatio {
+    const double* lrow; const double* zrow; double eps;
+    __device__ __forceinline__ double den(int j) const { return lrow[j]; }
+    __device__ __forceinline__ double num(int j) const { return zrow[j]; }
+    __device__ __forceinline__ double value(double a, double z) const { return a < -eps ? z / (-a) : __builtin_inf(); }
+};
 
 // ChooseEntering, Models/PrimalSimplex.cs:205-220: first index of the strict minimum of `v[0..L)`
 // (stride `stride`) below -eps, else -1.  Also used for the dual loop's leaving row (most negative
 // RHS, Models/DualSimplex.cs:45-55).
+template <int NT = SEL_NT>
 __device__ inline int block_first_min_below(const double* v, size_t stride, int L, double eps,
                                      double* s_v, int* s_i)
 {
     MinIdx m; m.v = -eps; m.i = INT_MAX;
-    for (int j = threadIdx.x; j < L; j += SEL_NT) {
+    for (int j = threadIdx.x; j < L; j += NT) {
         double x = v[(size_t)j * stride];
         if (x < m.v) { m.v = x; m.i = j; }
     }
-    m = block_min_idx(m, s_v, s_i);
+    m = block_min_idx<NT>(m, s_v, s_i);
     return m.i == INT_MAX ? -1 : m.i;
 }
 

@@ -20,7 +20,9 @@ struct DevState {
     int primal_count;    // pivots done in phase 2
     int forced_k;        // next entry of the forced-pivot list
     int qn;              // lookahead: entering column of the NEXT pivot (-1 = none), see lpx_select_la
-    int pad[6];
+    int c0n;             // multi-workgroup select: start column of the next forced search
+    int qn_valid;        // multi-workgroup select: 1 = `qn` above overrides the partial reduction
+    int pad[4];
 };
 
 enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
@@ -35,7 +37,9 @@ struct SelParams {
     int32_t* basis;      // [R-1]
     int32_t* trace;      // [2*trace_cap]
     int trace_cap;
-    DevState* st;
+    DevState* st;        // written by select (block 0), read by update and the host
+    DevState* us;        // multi-workgroup select: written by update (block 0), read by select
+    double* part_v; int32_t* part_i; int nblk;   // per-workgroup partial argmins of the lookahead scan
     double eps;          // Eps
     double tol_fdf;      // ratio hysteresis in phase 0
     double tol_dual;     // ratio hysteresis in phase 1
@@ -55,8 +59,11 @@ hipError_t launch_la_init(const SelParams& p, hipStream_t s);
 hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, double* fac0, double* fac1,
                          double* rhsbuf, const DevState* st, hipStream_t s,
                          hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// multi-workgroup protocol: select_mb (nblk workgroups) + update_mb (reduces the partials, commits `us`)
+hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
+hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+int select_mb_blocks(int C);
 hipError_t kernels_init();          // one-time function attributes
-int select_lds_doubles();           // capacity of the dynamic LDS ratio buffer
 
 void set_error(const std::string& msg);
 int ensure_device();                // binds a device and sets kernel attributes once

@@ -17,17 +17,14 @@ namespace lpx {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
 {
-    extern __shared__ __align__(16) double s_dyn[];
-    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
     __shared__ int s_i[SEL_NW];
-    __shared__ int s_out;
     __shared__ double s_piv;
 
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;              // uniform: loop already finished
 
-    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
     const int t = threadIdx.x;
     const int m = P.R - 1;
     const int rhs = P.C - 1;
@@ -48,11 +45,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
                 if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { phase = 1; continue; }
-                const int qq = q; const double eps = P.eps;
-                r = block_hysteresis_argmin(m, P.tol_fdf, [&](int i) {
-                        double a = T[(size_t)i * ld + qq];
-                        return a > eps ? T[(size_t)i * ld + rhs] / a : __builtin_inf(); },
-                    rbuf, s_list, s_v, s_i, &s_out);
+                r = block_hysteresis_argmin(m, P.tol_fdf, RowRatio{T + q, ld, T + rhs, ld, P.eps}, &s_out);
                 if (r < 0) { q = -1; phase = 1; continue; }
             } else if (phase == 1) {
                 // dual loop, Models/DualSimplex.cs:36-113
@@ -65,22 +58,14 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
                     }
                     final_status = LPX_OPTIMAL; break;
                 }
-                const int rr = r; const double eps = P.eps;
-                q = block_hysteresis_argmin(rhs, P.tol_dual, [&](int j) {
-                        double a = T[(size_t)rr * ld + j];
-                        return a < -eps ? T[(size_t)m * ld + j] / (-a) : __builtin_inf(); },
-                    rbuf, s_list, s_v, s_i, &s_out);
+                q = block_hysteresis_argmin(rhs, P.tol_dual, DualColRatio{T + (size_t)r * ld, T + (size_t)m * ld, P.eps}, &s_out);
                 if (q < 0) { r = -1; final_status = LPX_INFEASIBLE; break; }
             } else {
                 // primal loop, Models/PrimalSimplex.cs:92-124
                 if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { final_status = LPX_OPTIMAL; break; }
-                const int qq = q; const double eps = P.eps;
-                r = block_hysteresis_argmin(m, P.tol_primal, [&](int i) {
-                        double a = T[(size_t)i * ld + qq];
-                        return a > eps ? T[(size_t)i * ld + rhs] / a : __builtin_inf(); },
-                    rbuf, s_list, s_v, s_i, &s_out);
+                r = block_hysteresis_argmin(m, P.tol_primal, RowRatio{T + q, ld, T + rhs, ld, P.eps}, &s_out);
                 if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
             }
         }
@@ -145,7 +130,14 @@ struct ScanRule { int forced; double eps; double thresh; int c0; int C; };
     unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #define LPX_STAMP_END do { if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(P.ws)[14] += __builtin_amdgcn_s_memrealtime() - rt0_; \
     reinterpret_cast<unsigned long long*>(P.ws)[15] += 1; } } while (0)
+#define LPX_STAMP_MB(slot)                                                                     \
+    do { if (threadIdx.x == 0 && blockIdx.x == 1) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+         reinterpret_cast<unsigned long long*>(P.part_v + 128)[(slot)] += now_ - stamp_prev_; stamp_prev_ = now_; } } while (0)
+#define LPX_STAMP_END_MB do { if (threadIdx.x == 0 && blockIdx.x == 1) { reinterpret_cast<unsigned long long*>(P.part_v + 128)[14] += __builtin_amdgcn_s_memrealtime() - rt0_; \
+    reinterpret_cast<unsigned long long*>(P.part_v + 128)[15] += 1; } } while (0)
 #else
+#define LPX_STAMP_MB(slot) do {} while (0)
+#define LPX_STAMP_END_MB do {} while (0)
 #define LPX_STAMP(slot) do {} while (0)
 #define LPX_STAMP_BEGIN
 #define LPX_STAMP_END do {} while (0)
@@ -173,6 +165,7 @@ __device__ __forceinline__ int rule_decode(const ScanRule& R, const MinIdx& m)
 
 // Slow path (once per solve, or after a skipped forced pivot): pick the next column from T as it
 // stands and gather it plus the RHS column with strided reads.
+template <int NT = SEL_NT>
 __device__ int la_prepare_from_T(const SelParams& P, double* buf, int scanrow, const ScanRule& rule,
                                  double* s_v, int* s_i)
 {
@@ -181,11 +174,11 @@ __device__ int la_prepare_from_T(const SelParams& P, double* buf, int scanrow, c
     if (scanrow >= 0) {
         MinIdx b; rule_init(rule, b);
         const double* srow = P.T + (size_t)scanrow * ld;
-        for (int j = threadIdx.x; j < P.C; j += SEL_NT) rule_feed(rule, b, j, srow[j]);
-        b = block_min_idx(b, s_v, s_i);
+        for (int j = threadIdx.x; j < P.C; j += NT) rule_feed(rule, b, j, srow[j]);
+        b = block_min_idx<NT>(b, s_v, s_i);
         qn = rule_decode(rule, b);
     }
-    for (int i = threadIdx.x; i < P.R; i += SEL_NT) {
+    for (int i = threadIdx.x; i < P.R; i += NT) {
         if (qn >= 0) buf[i] = P.T[(size_t)i * ld + qn];
         P.rhsbuf[i] = P.T[(size_t)i * ld + (P.C - 1)];
     }
@@ -209,23 +202,23 @@ __global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P)
         rule.c0 = k < P.fcount ? P.fcols[k] : 0;
     }
     int qn = la_prepare_from_T(P, colc, scanrow, rule, s_v, s_i);
-    if (threadIdx.x == 0) st->qn = qn;
+    if (threadIdx.x == 0) {
+        st->qn = qn;
+        if (P.us) { *P.us = *st; P.us->qn = qn; }
+    }
 }
 
 __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
 {
-    extern __shared__ __align__(16) double s_dyn[];
-    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
     __shared__ int s_i[SEL_NW];
-    __shared__ int s_out;
 
     DevState* st = P.st;
     LPX_STAMP_BEGIN
     if (st->status != LPX_RUNNING) return;
     LPX_STAMP(0);
 
-    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
     const int t = threadIdx.x;
     const int m = P.R - 1;
     const size_t ld = (size_t)P.ld;
@@ -260,12 +253,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
         if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
         else if (q < 0) final_status = LPX_OPTIMAL;
         else {
-            const double eps = P.eps;
-            const double* rb = P.rhsbuf;
-            r = block_hysteresis_argmin(m, P.tol_primal, [&](int i) {
-                    double a = colc[i];
-                    return a > eps ? rb[i] / a : __builtin_inf(); },
-                rbuf, s_list, s_v, s_i, &s_out);
+            r = block_hysteresis_argmin(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps}, &s_out);
             if (r < 0) final_status = LPX_UNBOUNDED;
             scanrow = m;
         }
@@ -375,32 +363,249 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-workgroup select (primal and forced paths).
+//
+// lpx_select_la above is one 1024-lane workgroup: ~9.5 us per pivot at 1025x3073, of which the
+// barrier-heavy ratio scan is 4 us and the 3073 divisions plus the wait for the slowest wave another
+// 4.6 us (in-kernel stamps, tools/diag_select_stamps.py).  Here `nblk` 256-lane workgroups run the
+// same step: every workgroup repeats the ratio test (contiguous 8 B x 2 x m, L2-resident, identical
+// result everywhere), then normalises ONE column slice of the pivot row, scans the same slice of the
+// updated objective row and publishes a partial argmin.  The update kernel reduces the <= 64 partials
+// in every wave (one load + 6 DPP steps) to learn the next entering column.
+//
+// Two state records break what would otherwise be intra-kernel races:
+//   st  written by select workgroup 0, read by every update workgroup and by the host;
+//   us  written by update workgroup 0, read by every select workgroup.
+// Nothing is read and written by workgroups of the same launch, so no inter-workgroup fence is needed;
+// the kernel boundary orders the rest (placement-independent, cdna_hip_programming.md G16).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
+{
+    __shared__ int s_out;
+    __shared__ double s_v[MB_NT / 64];
+    __shared__ int s_i[MB_NT / 64];
+
+    const DevState* us = P.us;
+    DevState* st = P.st;
+    const int t = threadIdx.x, b = blockIdx.x;
+    LPX_STAMP_BEGIN
+    const int status_in = us->status;
+    if (status_in != LPX_RUNNING) { if (b == 0 && t == 0) st->status = status_in; return; }
+
+    LPX_STAMP_MB(0);
+    const int m = P.R - 1;
+    const size_t ld = (size_t)P.ld;
+    double* T = P.T;
+    const int iter = us->iter;
+    const int primal_count = us->primal_count;
+    double* colc = (iter & 1) ? P.col1 : P.col0;     // column q of the current tableau
+    const int q = us->qn;
+    int r = -1, scanrow = -1;
+    int final_status = LPX_RUNNING;
+    ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
+    rule.C = P.C; rule.c0 = 0;
+    const int k = us->forced_k;
+
+    if (rule.forced) {
+        if (k >= P.fcount) {
+            final_status = LPX_OPTIMAL;
+        } else {
+            r = P.frows[k];
+            scanrow = (k + 1 < P.fcount) ? P.frows[k + 1] : -1;
+            rule.c0 = (k + 1 < P.fcount) ? P.fcols[k + 1] : 0;
+            if (q < 0) {                                  // no eligible column: skip this pivot
+                if (b != 0) return;
+                int qn = la_prepare_from_T<MB_NT>(P, colc, scanrow, rule, s_v, s_i);
+                if (t == 0) {
+                    P.fchosen[k] = -1;
+                    st->status = LPX_RUNNING; st->iter = iter; st->r = -1; st->q = -1;
+                    st->forced_k = k + 1; st->primal_count = primal_count;
+                    st->qn = qn; st->qn_valid = 1; st->c0n = rule.c0;
+                }
+                return;
+            }
+        }
+    } else {
+        // primal loop head, Models/PrimalSimplex.cs:95-106
+        if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
+        else if (q < 0) final_status = LPX_OPTIMAL;
+        else {
+            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps});   // every wave, no barrier
+            if (r < 0) final_status = LPX_UNBOUNDED;
+            scanrow = m;
+        }
+    }
+    LPX_STAMP_MB(1);
+    if (final_status != LPX_RUNNING) {
+        if (b == 0 && t == 0) { st->status = final_status; st->iter = iter; st->r = -1; st->q = -1; }
+        return;
+    }
+
+    // this workgroup's column slice
+    const int per = (P.C + P.nblk - 1) / P.nblk;
+    const int j0 = b * per, j1 = min(P.C, j0 + per);
+    const double piv = colc[r];
+    const bool same = (scanrow == r);
+    const double fs = (scanrow >= 0 && !same) ? colc[scanrow] : 0.0;
+    double* trow = T + (size_t)r * ld;
+    const double* srow = T + (size_t)(scanrow >= 0 ? scanrow : 0) * ld;
+    MinIdx best; rule_init(rule, best);
+    for (int j = j0 + t; j < j1; j += MB_NT) {
+        const double p = trow[j] / piv;                       // true division, :250
+        trow[j] = p;
+        P.prow[j] = p;
+        if (scanrow >= 0) {
+            const double u = same ? p : srow[j] - fs * p;     // what lpx_update will store at T[s,j]
+            rule_feed(rule, best, j, u);
+        }
+    }
+    LPX_STAMP_MB(2);
+    best = wave_min_idx(best);                               // one partial per wave: no barrier, no LDS
+    LPX_STAMP_MB(3);
+    if ((t & 63) == 0) { P.part_v[b * (MB_NT / 64) + (t >> 6)] = best.v; P.part_i[b * (MB_NT / 64) + (t >> 6)] = best.i; }
+    if (t == 0) {
+        if (b == 0) {
+            if (rule.forced) P.fchosen[k] = q; else P.basis[r] = q;     // basis[leaving] = entering, :110
+            if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+            st->status = LPX_RUNNING;
+            st->iter = iter + 1; st->r = r; st->q = q;
+            st->primal_count = rule.forced ? primal_count : primal_count + 1;
+            st->forced_k = rule.forced ? k + 1 : k;
+            st->qn = -1; st->qn_valid = (scanrow >= 0) ? 0 : 1;         // no scan row: next column is "none"
+            st->c0n = rule.c0;
+        }
+    }
+    LPX_STAMP_MB(4);
+    LPX_STAMP_END_MB;
+}
+
+// lpx_update for the multi-workgroup protocol: same streaming body; the next entering column comes from
+// the select workgroups' partials, and workgroup 0 commits the state record `us` for the next select.
+__global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, int ld, int R, int C,
+                                                        const double* __restrict__ prow,
+                                                        double* fac0, double* fac1,
+                                                        double* __restrict__ rhsbuf,
+                                                        const DevState* __restrict__ st, DevState* us,
+                                                        const double* __restrict__ part_v,
+                                                        const int32_t* __restrict__ part_i, int nblk,
+                                                        int forced, int ncw, int nunits)
+{
+    const int status = st->status;
+    const int r = st->r;
+    const int lane = threadIdx.x & 63;
+    if (status != LPX_RUNNING) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { us->status = status; us->iter = st->iter; }
+        return;
+    }
+    // next entering column: override from select (skipped pivot / no scan row) or reduce the partials
+    int qn;
+    if (st->qn_valid) {
+        qn = st->qn;
+    } else {
+        MinIdx x; x.v = forced ? 0.0 : __builtin_inf(); x.i = INT_MAX;
+        const int npart = nblk * (MB_NT / 64);               // <= 128: one partial per select wave
+        if (lane < npart) { x.v = part_v[lane]; x.i = part_i[lane]; }
+        if (lane + 64 < npart) { MinIdx y; y.v = part_v[lane + 64]; y.i = part_i[lane + 64]; x = mi_pick(x, y); }
+        x = wave_min_idx(x);
+        if (x.i == INT_MAX) qn = -1;
+        else if (forced) { qn = st->c0n + x.i; if (qn >= C) qn -= C; }
+        else qn = x.i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        us->status = LPX_RUNNING; us->iter = st->iter; us->qn = qn;
+        us->primal_count = st->primal_count; us->forced_k = st->forced_k;
+    }
+    if (r < 0) return;                                   // skipped pivot: nothing to update
+    const int par = (st->iter - 1) & 1;
+    const double* __restrict__ fac = par ? fac1 : fac0;
+    double* __restrict__ nxt = par ? fac0 : fac1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    if (unit >= nunits) return;
+    const int cw = unit % ncw;
+    const int rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    if (col >= ld) return;
+    const double2 p = *reinterpret_cast<const double2*>(prow + col);
+    const int row0 = rb * UPD_ROWS;
+    double* base = T + (size_t)row0 * ld + col;
+    const bool wq = (qn >= 0) && ((qn & ~1) == col);
+    const bool wr = (((C - 1) & ~1) == col);
+
+    double2 v[UPD_ROWS];
+    double f[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R) {
+            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+            f[k] = fac[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R) {
+            double2 o;
+            if (i != r) {
+                o.x = v[k].x - f[k] * p.x;      // mul, then sub: contraction is off
+                o.y = v[k].y - f[k] * p.y;
+                *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
+            } else {
+                o = p;                          // row r already holds the normalised pivot row
+            }
+            if (wq) nxt[i] = (qn & 1) ? o.y : o.x;
+            if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-int select_lds_doubles() { return SEL_LDS_DOUBLES; }
-
-hipError_t kernels_init()
-{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SEL_LDS_DOUBLES * (int)sizeof(double));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select_la),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEL_LDS_DOUBLES * (int)sizeof(double));
-}
+hipError_t kernels_init() { return hipSuccess; }
 
 hipError_t launch_select(const SelParams& p, hipStream_t s)
 {
-    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
-    hipLaunchKernelGGL(lpx_select, dim3(1), dim3(SEL_NT), dyn, s, p);
+    hipLaunchKernelGGL(lpx_select, dim3(1), dim3(SEL_NT), 0, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_select_la(const SelParams& p, hipStream_t s)
 {
-    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
-    hipLaunchKernelGGL(lpx_select_la, dim3(1), dim3(SEL_NT), dyn, s, p);
+    hipLaunchKernelGGL(lpx_select_la, dim3(1), dim3(SEL_NT), 0, s, p);
+    return hipGetLastError();
+}
+
+int select_mb_blocks(int C)
+{
+    int b = (C + MB_NT - 1) / MB_NT;          // at least one column per lane and pass
+    if (b < 1) b = 1;
+    if (b > 32) b = 32;
+    return b;
+}
+
+hipError_t launch_select_mb(const SelParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_select_mb, dim3(p.nblk), dim3(MB_NT), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int ncw = (p.ld + 127) / 128;
+    const int nrb = (p.R + UPD_ROWS - 1) / UPD_ROWS;
+    const int nunits = ncw * nrb;
+    const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
+    const int forced = p.mode == MODE_FORCED ? 1 : 0;
+    if (e0 && e1)
+        hipExtLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C,
+                              (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                              (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+    else
+        hipLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, p.T, p.ld, p.R, p.C,
+                           (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                           (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     return hipGetLastError();
 }
 

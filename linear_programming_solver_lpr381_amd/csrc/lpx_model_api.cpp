@@ -58,6 +58,16 @@ int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts*
         auto fn = o->allreduce_max; void* u = o->allreduce_user;
         e.allreduce_max = [fn, u](double* v, int n) { fn(u, v, n); };
     }
+    if (o->test_node_lp) {
+        auto fn = o->test_node_lp; void* u = o->test_user;
+        e.test_node_lp = [fn, u](double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
+                                 double* x, double* z, int64_t* pivots) { return fn(u, T, R, C, basis, dual, repaired, max_iter, nvars, x, z, pivots); };
+    }
+    if (o->test_knap_relax) {
+        auto fn = o->test_knap_relax; void* u = o->test_user;
+        e.test_knap_relax = [fn, u](int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,
+                                    double* weight, int32_t* frac, double* fracval) { return fn(u, count, off, fidx, fval, profit, weight, frac, fracval); };
+    }
     UpdatePivot cb;
     if (o->text_cb) {
         auto fn = o->text_cb; void* u = o->text_user;

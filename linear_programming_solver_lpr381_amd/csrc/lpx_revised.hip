@@ -161,25 +161,17 @@ __global__ __launch_bounds__(256) void rv_ftran(RvParams P)
 // of W, and the basis bookkeeping of :121-124.  One workgroup.
 __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
 {
-    extern __shared__ __align__(16) double s_dyn[];
-    __shared__ int s_list[LIST_CAP];
+    __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
     __shared__ int s_i[SEL_NW];
-    __shared__ int s_out;
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
-    double* rbuf = P.rcap > 0 ? s_dyn : P.ws;
     const int t = threadIdx.x;
     const int m = P.m;
     const int iter = st->iter;
     const int q = st->q;
-    const double eps = P.eps;
     const double* d = P.fac;
-    const double* xb = P.rhsbuf;
-    const int r = block_hysteresis_argmin(m, P.tol, [&](int i) {
-            double di = d[i];
-            return di > eps ? xb[i] / di : __builtin_inf(); },
-        rbuf, s_list, s_v, s_i, &s_out);
+    const int r = block_hysteresis_argmin(m, P.tol, RowRatio{P.fac, 1, P.rhsbuf, 1, P.eps}, &s_out);
     if (r < 0) {                                                    // :113-118
         if (t == 0) { st->status = LPX_UNBOUNDED; st->r = -1; }
         return;
@@ -204,13 +196,6 @@ __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
         st->iter = iter + 1;
         st->r = r; st->qn = -1;
     }
-}
-
-hipError_t rv_kernels_init()
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(rv_select),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEL_LDS_DOUBLES * (int)sizeof(double));
 }
 
 }  // namespace lpx
@@ -239,7 +224,7 @@ static RvParams rv_params(lpx_revised* r, const lpx_run_opts* o)
     p.AT = r->AT; p.c = r->c; p.W = r->W; p.prow = r->prow; p.fac = r->fac; p.rhsbuf = r->rhsbuf;
     p.rc = r->rc; p.aq = r->aq; p.Bidx = r->Bidx; p.key = r->key; p.trace = r->trace; p.trace_cap = r->trace_cap;
     p.st = r->st; p.eps = o->eps; p.tol = o->ratio_tol; p.max_iter = o->max_iter;
-    p.ws = r->ws; p.rcap = (r->m + 1 <= select_lds_doubles()) ? r->m + 1 : 0;
+    p.ws = r->ws; p.rcap = 0;
     return p;
 }
 
@@ -248,8 +233,7 @@ static int rv_enqueue(lpx_revised* r, const RvParams& p, hipStream_t s, hipEvent
     hipLaunchKernelGGL(rv_price_dot, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
     hipLaunchKernelGGL(rv_price_pick, dim3(1), dim3(RV_NT), 0, s, p);
     hipLaunchKernelGGL(rv_ftran, dim3((p.m + 3) / 4), dim3(256), 0, s, p);
-    size_t dyn = p.rcap > 0 ? (size_t)p.rcap * sizeof(double) : 0;
-    hipLaunchKernelGGL(rv_select, dim3(1), dim3(SEL_NT), dyn, s, p);
+    hipLaunchKernelGGL(rv_select, dim3(1), dim3(SEL_NT), 0, s, p);
     LPX_HIP_TRY(hipGetLastError());
     LPX_HIP_TRY(launch_update(p.W, p.ldw, p.m + 1, p.m + 1, p.prow, p.fac, p.fac, p.rhsbuf, p.st, s, e0, e1));
     return 0;
@@ -276,9 +260,6 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     if (!out || m < 1 || n < 1 || !A || !c || !b) { set_error("lpx_revised_create: bad argument"); return LPX_EINVAL; }
     int rc = ensure_device();
     if (rc) return rc;
-    static std::once_flag once; static hipError_t ierr = hipSuccess;
-    std::call_once(once, [] { ierr = rv_kernels_init(); });
-    if (ierr != hipSuccess) { set_error("rv_select attribute setup failed"); return LPX_EDEVICE; }
     lpx_revised* r = new lpx_revised();
     r->m = m; r->n = n;
     r->ldat = (m + 15) / 16 * 16;

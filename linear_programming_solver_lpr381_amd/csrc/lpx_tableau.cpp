@@ -2,6 +2,7 @@
 // (C ABI of include/lpx.h).  Host code only: kernels live in lpx_kernels.hip.
 #include "lpx_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -18,7 +19,10 @@ struct lpx_tableau {
     double* col0 = nullptr;     // [R] lookahead column buffers (ping-pong)
     double* col1 = nullptr;
     double* rhsbuf = nullptr;   // [R]
-    double* ws = nullptr;       // [max(R,C)]
+    double* ws = nullptr;       // [MB_MAXB * max(R,C)]
+    double* part_v = nullptr; int32_t* part_i = nullptr;   // [64] partial argmins of the multi-workgroup select
+    DevState* us = nullptr;     // state record written by the update kernel (multi-workgroup protocol)
+    int use_mb = 1;
     int32_t* basis = nullptr;   // [R-1]
     int32_t* snapBasis = nullptr;
     int32_t* trace = nullptr;   // [2*trace_cap]
@@ -116,7 +120,10 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     ALLOC(t->col0, sizeof(double) * R);
     ALLOC(t->col1, sizeof(double) * R);
     ALLOC(t->rhsbuf, sizeof(double) * R);
-    ALLOC(t->ws, sizeof(double) * wsn);
+    ALLOC(t->ws, sizeof(double) * (size_t)wsn * 32);
+    ALLOC(t->part_v, sizeof(double) * 192);   // [128..191]: diagnostic stamps (LPX_STAMPS builds only)
+    ALLOC(t->part_i, sizeof(int32_t) * 128);
+    ALLOC(t->us, sizeof(DevState));
     ALLOC(t->basis, sizeof(int32_t) * (R > 1 ? R - 1 : 1));
     ALLOC(t->trace, sizeof(int32_t) * 2 * t->trace_cap);
     ALLOC(t->st, sizeof(DevState));
@@ -146,7 +153,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     if (t->stream) hipStreamSynchronize(t->stream);
     drop_graph(t);
     for (hipEvent_t e : t->events) hipEventDestroy(e);
-    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws);
+    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws); hipFree(t->part_v); hipFree(t->part_i); hipFree(t->us);
     hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen);
     if (t->hst) hipHostFree(t->hst);
@@ -225,8 +232,9 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
 #ifdef LPX_STAMPS
 int lpx_debug_ws(lpx_tableau* t, unsigned long long* out, int n, int clear)
 {
-    LPX_HIP_TRY(hipMemcpy(out, t->ws, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
-    if (clear) LPX_HIP_TRY(hipMemset(t->ws, 0, sizeof(unsigned long long) * n));
+    double* src = t->us ? t->part_v + 128 : t->ws;
+    LPX_HIP_TRY(hipMemcpy(out, src, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (clear) LPX_HIP_TRY(hipMemset(src, 0, sizeof(unsigned long long) * n));
     return 0;
 }
 #endif
@@ -258,6 +266,9 @@ int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e
     if (p.mode == MODE_DUAL) {
         LPX_HIP_TRY(launch_select(p, s));
         LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->pcol, t->pcol, nullptr, t->st, s, e0, e1));
+    } else if (p.us) {
+        LPX_HIP_TRY(launch_select_mb(p, s));
+        LPX_HIP_TRY(launch_update_mb(p, s, e0, e1));
     } else {
         LPX_HIP_TRY(launch_select_la(p, s));
         LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->col0, t->col1, t->rhsbuf, t->st, s, e0, e1));
@@ -299,8 +310,11 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
     p.tol_primal = (mode == MODE_DUAL) ? o->eps : o->ratio_tol;
     p.max_iter = o->max_iter; p.fdf_guard = o->fdf_guard; p.cleanup = o->cleanup; p.mode = mode;
     p.ws = t->ws;
-    const int need = t->R > t->C ? t->R : t->C;
-    p.rcap = need <= select_lds_doubles() ? need : 0;
+    p.rcap = 0;
+    static const bool mb_env = [] { const char* e = std::getenv("LPX_SELECT_MB"); return !(e && e[0] == '0'); }();
+    if (mode != MODE_DUAL && mb_env && t->use_mb) {
+        p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->C);
+    }
     return p;
 }
 

@@ -123,6 +123,10 @@ class LPSolver:             # Models/LPSolver.cs:6-77
                 cb = _lib.ALLREDUCE_CB(_ar)
                 keep.append(cb)
                 o.allreduce_max = cb
+            elif k in ("test_node_lp", "test_knap_relax"):
+                cb = (_lib.TEST_NODE_LP if k == "test_node_lp" else _lib.TEST_KNAP_RELAX)(v)
+                keep.append(cb)
+                setattr(o, k, cb)
             elif hasattr(o, k):
                 setattr(o, k, v)
             else:

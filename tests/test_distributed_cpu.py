@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 path (frontier sharding + one all-reduce(max) per level / round +
+termination + final ownership of x) of the product's host logic.  See tests/_dist_worker.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_bnb_and_knapsack(tmp_path, lpx, oracle):
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"r{r}.json")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), "2", out], env=env))
+    for p in procs:
+        assert p.wait(timeout=280) == 0
+    res = [json.load(open(o)) for o in outs]
+    for r in res:
+        # same optimum as the reference-order DFS of the oracle, on every rank
+        assert r["bnb"]["z"] == r["bnb_ref"]["z"]
+        assert r["knap"]["z"] == r["knap_ref"]["z"]
+        assert r["knap"]["feasible"] and r["knap"]["value"] == r["knap"]["z"]
+    # both ranks end with the same published solution vectors
+    assert res[0]["bnb"]["x"] == res[1]["bnb"]["x"]
+    assert res[0]["knap"]["x"] == res[1]["knap"]["x"]
+    # the collective really ran, the same number of times on both ranks (no rank left a level early)
+    assert res[0]["bnb"]["allreduces"] == res[1]["bnb"]["allreduces"] >= 3
+    assert res[0]["knap"]["allreduces"] == res[1]["knap"]["allreduces"] >= 2
+    # the work was actually split: neither rank solved every node alone
+    tot = res[0]["bnb"]["lp_solves"] + res[1]["bnb"]["lp_solves"]
+    assert res[0]["bnb"]["lp_solves"] < tot and res[1]["bnb"]["lp_solves"] < tot
+
+
+def test_single_process_level_search_with_seam_matches_oracle(lpx, oracle):
+    import numpy as np
+    sys.path.insert(0, HERE)
+    from _dist_worker import node_lp
+    g = np.random.default_rng(5)
+    n, m = 9, 4
+    A = g.integers(0, 10, size=(m, n)).astype(float)
+    b = np.floor(0.5 * A.sum(axis=1))
+    c = g.integers(1, 21, size=n).astype(float)
+    Af = np.vstack([A, np.eye(n)]); bf = np.concatenate([b, np.ones(n)])
+    p = lpx.LPProblem.from_arrays(0, c, Af, np.zeros(m + n, int), bf)
+    for mode in (0, 1):
+        ref = oracle.bnb_solve(oracle.Problem(oracle.MAX, c, Af, np.zeros(m + n, np.int32), bf), mode)
+        dfs = lpx.BranchAndBound(bnb_mode=mode, bnb_search=0, test_node_lp=node_lp).Solve(p)
+        assert dfs.NodeLog.tolist() == ref.log.tolist() and dfs.LpSolves == ref.lp_solves
+        lvl = lpx.BranchAndBound(bnb_mode=mode, bnb_search=1, concurrent_nodes=3, test_node_lp=node_lp).Solve(p)
+        if ref.has_incumbent:
+            assert dfs.OptimalValue == ref.best_z
+            if mode == 1:
+                assert lvl.OptimalValue == ref.best_z

@@ -21,6 +21,7 @@ dt.primal_run()
 dt.restore()
 out = (C.c_ulonglong * 16)()
 lib.lpx_debug_ws(dt._h, out, 16, 1)
+
 status, st = dt.primal_run(use_graph=1, batch=64)
 lib.lpx_debug_ws(dt._h, out, 16, 0)
 v = list(out)
@@ -32,3 +33,4 @@ clk = tot / (v[14] / 100e6) / 1e9 if v[14] else 0
 print(f"in-kernel clock ~{clk:.2f} GHz; total stamped {tot/calls:.0f} cycles/call = {tot/calls/clk/1e3:.2f} us")
 for nm, x in zip(names, v[:5]):
     print(f"  {nm:34s} {x/calls:9.0f} cycles  {100*x/tot:5.1f}%")
+
