@@ -38,6 +38,24 @@ METRIC = "simplex pivots/sec on dense m×n tableau; B&B nodes/sec at 1/2/4/8 GPU
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic(R, C):
+    """HBM bytes per launch of the update kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs of tools/k4_headline.py, FETCH doubled per the gfx950
+    correction of MI355X_MICROARCH.md; tools/pmc_summarise.py).  PMC collection needs rocprofv3 around
+    the process, so it cannot happen inside this script; None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ld = (C + 15) // 16 * 16
+    units = ((ld + 127) // 128) * ((R + 7) // 8)
+    grid = ((units + 3) // 4) * 256
+    d = json.load(open(path))
+    for k, v in d.items():
+        if k.endswith(f"@grid{grid}"):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,8 +208,8 @@ def main():
         k_ms = pst["update_ms_sum"] / max(pst["update_launches"], 1)
         alg = 16.0 * R * C
         ach = alg / (k_ms * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "lpx_update", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        out["roofline"] = {"kernel": "lpx_update_mb", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(R, C),
                            "avg_kernel_us": 1e3 * k_ms, "launches": pst["update_launches"],
                            "algorithmic_bytes_per_launch": alg,
                            "note": "25 MB tableau: resident in the 256 MiB Infinity Cache, not an HBM stream; "
@@ -208,9 +226,9 @@ def main():
         hach = halg / (hk_ms * 1e-3) / 1e9
         hd.upload(Th)
         _, hst2 = hd.forced_pivots(rows[20:], cols[20:], 0.1, batch=100)
-        out["roofline_headline"] = {"kernel": "lpx_update", "shape": [HR, HC], "bound": "hbm",
+        out["roofline_headline"] = {"kernel": "lpx_update_mb", "shape": [HR, HC], "bound": "hbm",
                                     "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": hach / HBM_PEAK_GBS, "traffic": None,
+                                    "frac": hach / HBM_PEAK_GBS, "traffic": pmc_traffic(HR, HC),
                                     "avg_kernel_us": 1e3 * hk_ms, "launches": hst["update_launches"],
                                     "algorithmic_bytes_per_launch": halg,
                                     "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}

@@ -1,0 +1,22 @@
+"""Runs the rank-1 update kernel on the headline shape (raw 4096x8192 tableau, forced pivots) and on
+config 2 (full solve) -- the target of the rocprofv3 --pmc passes whose results go to profiles/."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import linear_programming_solver_lpr381_amd as L
+from linear_programming_solver_lpr381_amd import synth
+
+L._lib.check(L._lib.lib().lpx_init(0))
+npiv = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+HR, HC = 4096, 8192
+hd = L.DeviceTableau.from_host(synth.raw_tableau(HR, HC))
+rows, cols = synth.forced_pivot_list(HR, HC, npiv)
+_, st = hd.forced_pivots(rows, cols, 0.1, use_graph=0, batch=20)
+print("headline pivots", st["pivots"])
+hd.close()
+c, A, b = synth.dense_lp(1024, 2048)
+T, basis = synth.primal_tableau_from(c, A, b)
+dt = L.DeviceTableau.from_host(T, basis)
+status, st = dt.primal_run(use_graph=0, batch=64, max_iter=600)
+print("cfg2 pivots", st["pivots"], "status", status)
+dt.close()
