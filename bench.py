@@ -68,9 +68,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline value")
     ap.add_argument("--headline-pivots", type=int, default=200)
     ap.add_argument("--cpu-sample-pivots", type=int, default=10000)
-    ap.add_argument("--bnb-nodes", type=int, default=48, help="node budget per rank (config 4 leg)")
-    ap.add_argument("--bnb-concurrent", type=int, default=8)
-    ap.add_argument("--knap-nodes", type=int, default=40000, help="pop budget per rank (config 5 leg)")
+    ap.add_argument("--bnb-nodes", type=int, default=400, help="node budget per rank (config 4 leg)")
+    ap.add_argument("--bnb-concurrent", type=int, default=32)
+    ap.add_argument("--knap-nodes", type=int, default=200000, help="pop budget per rank (config 5 leg)")
     ap.add_argument("--revised-iters", type=int, default=300)
     args = ap.parse_args()
 

@@ -97,6 +97,9 @@ int  lpx_tableau_restore(lpx_tableau* t);        /* D2D restore from the snapsho
 int  lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld);
 int  lpx_tableau_trace(lpx_tableau* t, int32_t* trace /* [2*cap] */, int cap, int* n);
 int  lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld);
+/* A handle created for (Rcap, Ccap) can hold any smaller tableau: the kernels read the live shape from a
+ * device record, so one handle (and its captured hipGraph) serves every depth of a B&B tree. */
+int  lpx_tableau_set_shape(lpx_tableau* t, int R, int C);
 
 /* The hot loops.  Each iteration is two launches on one stream:
  *   select  -- ChooseEntering + ChooseLeaving (+ pivot-row normalisation and pivot-column snapshot)
@@ -119,6 +122,16 @@ int lpx_forced_pivots_run(lpx_tableau* t, const int32_t* rows, const int32_t* co
 /* x[basis[i]] = T[i,last] for basis[i] < nvars, *z = T[m,last] (FinalizeReport,
  * Models/PrimalSimplex.cs:130-138) without downloading the tableau. */
 int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z);
+
+/* Node assembly on the device: `node` becomes the tableau
+ * BuildTableau (Models/PrimalSimplex.cs:179-203) would produce for the root model plus `ncuts` unit
+ * rows (Models/Branch&Bound.cs:233-248); the node handle needs capacity for root shape + ncuts and takes
+ * that shape.  Row k has coef[k] at column var[k], zero[k] (a signed zero: the
+ * reference's `A[j] *= -1` turns 0 into -0) elsewhere, its own slack, and rhs[k].  `root` holds the
+ * prepared root tableau (its snapshot if one was taken) and is not modified.  Stream-ordered with
+ * the run that follows on `node`. */
+int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts, const int32_t* var,
+                           const double* coef, const double* zero, const double* rhs);
 
 /* Branch-and-bound node batches: runs `count` independent tableaux to completion,
  * interleaving their batches on their own streams so that small node LPs overlap on one GPU.

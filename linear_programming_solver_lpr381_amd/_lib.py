@@ -132,6 +132,8 @@ def lib() -> C.CDLL:
     L.lpx_revised_solve.argtypes = [dp, C.c_int, C.c_int, dp, dp, ip, ip, dp, dp, C.c_double, C.c_int,
                                     PIVOT_CB, vp, C.POINTER(Stats)]
     L.lpx_tableau_solution.argtypes = [vp, C.c_int, dp, dp]
+    L.lpx_tableau_set_shape.argtypes = [vp, C.c_int, C.c_int]
+    L.lpx_tableau_build_node.argtypes = [vp, vp, C.c_int, ip, dp, dp, dp]
     L.lpx_multi_run.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),
                                 C.POINTER(C.c_int), C.POINTER(Stats)]
     L.lpx_knapsack_create.argtypes = [dp, dp, C.c_int, C.c_double, C.POINTER(vp)]

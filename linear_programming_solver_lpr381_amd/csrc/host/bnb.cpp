@@ -45,9 +45,11 @@ struct HandlePool {
         int rc = lpx_tableau_create(R, C, &t);
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         all_.push_back(t);
+        cap_[t] = {R, C};
         return t;
     }
-    void put(lpx_tableau* t) { int R, C; lpx_tableau_shape(t, &R, &C, nullptr); free_[{R, C}].push_back(t); }
+    std::map<lpx_tableau*, std::pair<int, int>> cap_;
+    void put(lpx_tableau* t) { free_[cap_[t]].push_back(t); }
     ~HandlePool() { for (lpx_tableau* t : all_) lpx_tableau_destroy(t); }
 };
 
@@ -57,8 +59,9 @@ struct NodeLP {
     int status = LPX_OPTIMAL;
     std::vector<double> x; double z = 0.0;
     int64_t pivots = 0;
-    // prepared tableau
+    // prepared tableau (host path: test seam) or branching-row descriptors (device assembly)
     std::vector<double> T; int R = 0, C = 0; std::vector<int32_t> basis; bool dual = false;
+    bool on_device = false; std::vector<int32_t> cvar; std::vector<double> ccoef, czero, crhs;
     lpx_tableau* h = nullptr;
 };
 
@@ -66,6 +69,9 @@ struct Ctx {
     const LPProblem* root; EngineOptions opt; UpdatePivot cb;
     double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
     SimplexResult* out; HandlePool pool; bool stop = false;
+    // resident root templates: the prepared root tableau as the primal / dual path builds it
+    lpx_tableau* root_tpl[2] = {nullptr, nullptr}; int tplR[2] = {0, 0}, tplC[2] = {0, 0}; bool tpl_bad[2] = {false, false};
+    ~Ctx() { lpx_tableau_destroy(root_tpl[0]); lpx_tableau_destroy(root_tpl[1]); }
     void log(const std::string& s) { if (cb) cb(s + "\n", nullptr); }
 };
 
@@ -92,14 +98,23 @@ bool IsIntegral(const std::vector<double>& x)                     // :268-274
     return true;
 }
 
-bool IsFeasible(const std::vector<double>& x, const LPProblem& problem)   // :276-294
+// IsFeasible, :276-294, on the node = root constraints followed by its branching rows (same order as
+// the cloned problem of the reference, without materialising the clone)
+bool IsFeasible(const std::vector<double>& x, const LPProblem& root, const std::vector<Cut>& cuts)
 {
-    for (const Constraint& c : problem.Constraints) {
+    for (const Constraint& c : root.Constraints) {
         double sum = 0;
         for (size_t i = 0; i < x.size(); ++i) sum += c.A[i] * x[i];
         if (c.Relation == Rel::LE && sum > c.B + EPS) return false;
         if (c.Relation == Rel::GE && sum < c.B - EPS) return false;
         if (c.Relation == Rel::EQ && std::fabs(sum - c.B) > EPS) return false;
+    }
+    for (const Cut& k : cuts) {
+        double sum = 0;                                     // UnitVector row: 0*x_i terms add exact zeros
+        for (size_t i = 0; i < x.size(); ++i) sum += ((int)i == k.var ? 1.0 : 0.0) * x[i];
+        if (k.rel == Rel::LE && sum > k.bound + EPS) return false;
+        if (k.rel == Rel::GE && sum < k.bound - EPS) return false;
+        if (k.rel == Rel::EQ && std::fabs(sum - k.bound) > EPS) return false;
     }
     for (double v : x) if (v < -EPS) return false;
     return true;
@@ -125,8 +140,68 @@ void prepare(const Ctx& c, const LPProblem& p, NodeLP& lp)
     } catch (const LpxException&) { lp.error = true; }
 }
 
+// Device assembly: the root part of every node tableau is identical, so it is prepared and uploaded
+// once per path (primal: ExpandEqualities + BuildTableau; dual: PrepareForTableau + BuildTableau) and a
+// node only ships its branching rows.  Returns false when the root part itself throws in the reference
+// (then every node of that path throws the same way).
+bool ensure_template(Ctx& c, bool dual)
+{
+    const int w = dual ? 1 : 0;
+    if (c.root_tpl[w] || c.tpl_bad[w]) return !c.tpl_bad[w];
+    std::vector<double> T; int R, C; std::vector<int32_t> basis; std::vector<std::string> names;
+    try {
+        if (!dual) {
+            LPProblem model = c.root->Clone();
+            if (model.ObjectiveSense == Sense::Min) for (double& v : model.C) v = -v;
+            for (const Constraint& k : model.Constraints) if (k.B < -1e-9) { c.tpl_bad[w] = true; return false; }
+            BuildTableauPrimal(ExpandEqualitiesToInequalities(model), T, R, C, basis, names);
+        } else {
+            BuildTableauPrimal(PrepareForTableauDual(*c.root, c.opt.bnb_mode == 1), T, R, C, basis, names);
+        }
+    } catch (const LpxException&) { c.tpl_bad[w] = true; return false; }
+    int rc = lpx_tableau_create(R, C, &c.root_tpl[w]);
+    if (rc) throw LpxException(rc, "liblpx: " + last_error());
+    rc = lpx_tableau_upload(c.root_tpl[w], T.data(), basis.data());
+    if (rc) throw LpxException(rc, "liblpx: " + last_error());
+    c.tplR[w] = R; c.tplC[w] = C;
+    return true;
+}
+
+// branching rows exactly as PrimalSimplex.Solve / PrepareForTableau would leave them
+void prepare_device(Ctx& c, const std::vector<Cut>& cuts, NodeLP& lp)
+{
+    lp.dual = has_ge_or_eq(*c.root);
+    for (const Cut& k : cuts) if (k.rel != Rel::LE) lp.dual = true;
+    if (!ensure_template(c, lp.dual)) { lp.error = true; return; }
+    const int w = lp.dual ? 1 : 0;
+    const bool fix_d1 = c.opt.bnb_mode == 1;
+    for (const Cut& k : cuts) {
+        double a = 1.0, z = 0.0, B = k.bound;
+        if (!lp.dual) {
+            if (B < -1e-9) { lp.error = true; return; }              // "negative RHS" exception, PrimalSimplex.cs:73-76
+        } else {
+            if (k.rel == Rel::GE) { a *= -1; z *= -1; B *= -1; }      // DualSimplex.cs:141-147
+            if (!fix_d1 && B < -1e-9) { a *= -1; z *= -1; B *= -1; }  // :148-153 (defect D1)
+        }
+        lp.cvar.push_back(k.var); lp.ccoef.push_back(a); lp.czero.push_back(z); lp.crhs.push_back(B);
+    }
+    lp.R = c.tplR[w] + (int)cuts.size(); lp.C = c.tplC[w] + (int)cuts.size();
+    lp.on_device = true;
+}
+
 void upload(Ctx& c, NodeLP& lp)
 {
+    if (lp.on_device) {
+        // capacity classes of 32 levels: one set of handles (and captured graphs) serves 32 depths
+        const int d = (int)lp.cvar.size(), w = lp.dual ? 1 : 0;
+        const int capd = (d + 31) / 32 * 32 + (d % 32 == 0 && d > 0 ? 0 : 0);
+        const int slack = capd > 0 ? capd : 32;
+        lp.h = c.pool.get(c.tplR[w] + slack, c.tplC[w] + slack);
+        int rc = lpx_tableau_build_node(lp.h, c.root_tpl[lp.dual ? 1 : 0], (int)lp.cvar.size(), lp.cvar.data(),
+                                        lp.ccoef.data(), lp.czero.data(), lp.crhs.data());
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        return;
+    }
     lp.h = c.pool.get(lp.R, lp.C);
     int rc = lpx_tableau_upload(lp.h, lp.T.data(), lp.basis.data());
     if (rc) throw LpxException(rc, "liblpx: " + last_error());
@@ -204,7 +279,7 @@ void set_incumbent(Ctx& c, const std::vector<double>& x, double z)
 
 // The decision part of SolveNode (:156-230) for a solved relaxation.  Returns the branching
 // variable (>= 0) when the node branches, else -1.
-int decide(Ctx& c, const LPProblem& p, const NodeLP& lp, int depth, const std::string& name, int& floorVal, int& ceilVal)
+int decide(Ctx& c, const std::vector<Cut>& cuts, const NodeLP& lp, int depth, const std::string& name, int& floorVal, int& ceilVal)
 {
     if (lp.error) { c.log(name + ": LP relaxation infeasible or error"); node_log(c, depth, O_ERROR, -1, 0.0); return -1; }
     if (!lp.has_solution) {
@@ -214,7 +289,7 @@ int decide(Ctx& c, const LPProblem& p, const NodeLP& lp, int depth, const std::s
     if (c.opt.bnb_mode == 1 && lp.status == LPX_INFEASIBLE) { node_log(c, depth, O_LP_INFEASIBLE, -1, lp.z); return -1; }
     const std::vector<double>& x = lp.x; const double z = lp.z;
     if (c.cb) c.log(name + " LP solution: z* = " + FormatF(z, 3));
-    if (!IsFeasible(x, p)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
+    if (!IsFeasible(x, *c.root, cuts)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
     const double bestObj = c.has_best ? c.best : -INFINITY;
     if (z <= bestObj + EPS) { c.log(name + ": Pruned by bound (z* <= current best " + FormatF(bestObj, 3) + ")."); node_log(c, depth, O_PRUNED, -1, z); return -1; }   // :182-186
     if (IsIntegral(x)) {                                                     // :189-195
@@ -246,12 +321,12 @@ void SolveNode(Ctx& c, std::vector<Cut>& cuts, int depth, const std::string& nam
     if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { c.stop = true; return; }
     c.out->Nodes++;
     if (depth > MaxDepth) { c.log(name + ": Maximum recursion depth reached -> prune."); node_log(c, depth, O_DEPTH, -1, 0.0); return; }
-    LPProblem p = make_node(*c.root, cuts);
-    NodeLP lp; prepare(c, p, lp);
+    NodeLP lp;
+    if (c.opt.test_node_lp) prepare(c, make_node(*c.root, cuts), lp); else prepare_device(c, cuts, lp);
     std::vector<NodeLP*> g{&lp};
-    solve_group(c, g, p.NumVars());
+    solve_group(c, g, c.root->NumVars());
     int fl = 0, ce = 0;
-    int k = decide(c, p, lp, depth, name, fl, ce);
+    int k = decide(c, cuts, lp, depth, name, fl, ce);
     if (k < 0) return;
     cuts.push_back({k, Rel::GE, (double)ce});
     SolveNode(c, cuts, depth + 1, "Subproblem: x" + std::to_string(k + 1) + " >= " + std::to_string(ce));   // ceil first, :256
@@ -278,16 +353,14 @@ void LevelSearch(Ctx& c)
             replicated = false;
         }
         // solve this level
-        std::vector<LPProblem> probs; probs.reserve(frontier.size());
         std::vector<NodeLP> lps(frontier.size());
         std::vector<NodeLP*> group;
         std::vector<char> skip(frontier.size(), 0);
         for (size_t i = 0; i < frontier.size(); ++i) {
-            probs.push_back(make_node(*c.root, frontier[i].cuts));
             if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
             c.out->Nodes++;
             if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
-            prepare(c, probs[i], lps[i]);
+            if (c.opt.test_node_lp) prepare(c, make_node(*c.root, frontier[i].cuts), lps[i]); else prepare_device(c, frontier[i].cuts, lps[i]);
             group.push_back(&lps[i]);
         }
         solve_group(c, group, c.root->NumVars());
@@ -296,7 +369,7 @@ void LevelSearch(Ctx& c)
             if (skip[i] == 1) continue;
             if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
             int fl = 0, ce = 0;
-            int k = decide(c, probs[i], lps[i], frontier[i].depth, "Node", fl, ce);
+            int k = decide(c, frontier[i].cuts, lps[i], frontier[i].depth, "Node", fl, ce);
             if (k < 0) continue;
             FNode up{frontier[i].cuts, frontier[i].depth + 1}; up.cuts.push_back({k, Rel::GE, (double)ce});
             FNode dn{frontier[i].cuts, frontier[i].depth + 1}; dn.cuts.push_back({k, Rel::LE, (double)fl});
@@ -384,7 +457,7 @@ SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot update
         BestObjective = out.OptimalValue; BestSolution = c.best_x; HasBest = c.has_best;
     };
 
-    if (IsIntegral(xRoot) && IsFeasible(xRoot, problem)) {                                // :85-91
+    if (IsIntegral(xRoot) && IsFeasible(xRoot, problem, {})) {                                // :85-91
         set_incumbent(c, xRoot, zRoot);
         c.log("Root Problem is already integral and feasible. Branch & Bound not required.");
         BuildReport();

@@ -31,7 +31,7 @@ std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b;
 struct Relax { double profit = 0, weight = 0, fracval = 0; int frac = -1; bool valid = false; };
 
 struct KNode {
-    std::vector<int32_t> idx; std::vector<int8_t> val;      // decisions in branching order
+    std::vector<int32_t> idx; std::vector<int8_t> val;      // fixed decisions, ascending item index
     double bound = 0; Relax self;                          // own relaxation (bound == self.profit)
     Relax child[2];                                        // cached children (x=0, x=1)
 };
@@ -78,12 +78,14 @@ struct Search {
         if (jobs.empty()) return;
         std::vector<int32_t> off(jobs.size() + 1, 0), fidx; std::vector<int8_t> fval;
         for (size_t j = 0; j < jobs.size(); ++j) {
-            const KNode* nd = jobs[j].node;
-            std::vector<std::pair<int32_t, int8_t>> f;
-            for (size_t e = 0; e < nd->idx.size(); ++e) f.emplace_back(nd->idx[e], nd->val[e]);
-            if (jobs[j].item >= 0) f.emplace_back(jobs[j].item, (int8_t)jobs[j].v);
-            std::sort(f.begin(), f.end());                  // original index ascending (:442)
-            for (auto& pr : f) { fidx.push_back(pr.first); fval.push_back(pr.second); }
+            const KNode* nd = jobs[j].node;              // nd->idx is kept in ascending index order (:442)
+            const int it = jobs[j].item;
+            bool placed = it < 0;
+            for (size_t e = 0; e < nd->idx.size(); ++e) {
+                if (!placed && it < nd->idx[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
+                fidx.push_back(nd->idx[e]); fval.push_back(nd->val[e]);
+            }
+            if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
             off[j + 1] = (int32_t)fidx.size();
         }
         std::vector<double> p(jobs.size()), w(jobs.size()), fv(jobs.size()); std::vector<int32_t> fr(jobs.size());
@@ -137,8 +139,13 @@ struct Search {
                 }
             } else {                                                        // :239-248
                 NodeP ch(new KNode());
-                ch->idx = node->idx; ch->val = node->val;
-                ch->idx.push_back(item); ch->val.push_back((int8_t)v);
+                ch->idx.reserve(node->idx.size() + 1); ch->val.reserve(node->idx.size() + 1);
+                bool placed = false;                                        // keep ascending index order
+                for (size_t e = 0; e < node->idx.size(); ++e) {
+                    if (!placed && item < node->idx[e]) { ch->idx.push_back(item); ch->val.push_back((int8_t)v); placed = true; }
+                    ch->idx.push_back(node->idx[e]); ch->val.push_back(node->val[e]);
+                }
+                if (!placed) { ch->idx.push_back(item); ch->val.push_back((int8_t)v); }
                 ch->bound = r.profit; ch->self = r;
                 pq.push(ch.get());
                 store.push_back(std::move(ch));

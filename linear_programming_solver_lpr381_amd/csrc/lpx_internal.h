@@ -28,7 +28,8 @@ struct DevState {
 enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
 
 struct SelParams {
-    double* T; int ld; int R; int C;
+    double* T; int ld; int R; int C;    // R, C: CAPACITY of the handle (grid sizing)
+    const int32_t* shape;               // device record {R, C} of the tableau currently in the handle
     double* prow;        // [ld]  normalised pivot row  T[r,:]/T[r,q]
     double* pcol;        // [R]   pivot column snapshot T[:,q]        (dual path)
     double* col0;        // [R]   lookahead column buffers, ping-pong   (primal / forced path)
@@ -56,13 +57,16 @@ hipError_t launch_select_la(const SelParams& p, hipStream_t s);    // lookahead 
 hipError_t launch_la_init(const SelParams& p, hipStream_t s);
 // fac0/fac1: factor columns, chosen by pivot parity; nxt by-products go to the other one.
 // e0/e1 non-null: bracket the dispatch with HIP events bound to the kernel (hipExtLaunchKernelGGL).
-hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, double* fac0, double* fac1,
+hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, const double* prow, double* fac0, double* fac1,
                          double* rhsbuf, const DevState* st, hipStream_t s,
                          hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 // multi-workgroup protocol: select_mb (nblk workgroups) + update_mb (reduces the partials, commits `us`)
 hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int select_mb_blocks(int C);
+hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,
+                             const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
+                             int32_t* basis, hipStream_t s);
 hipError_t kernels_init();          // one-time function attributes
 
 void set_error(const std::string& msg);

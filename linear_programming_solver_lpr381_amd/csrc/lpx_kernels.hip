@@ -26,8 +26,9 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
     if (st->status != LPX_RUNNING) return;              // uniform: loop already finished
 
     const int t = threadIdx.x;
-    const int m = P.R - 1;
-    const int rhs = P.C - 1;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    const int m = R - 1;
+    const int rhs = C - 1;
     const size_t ld = (size_t)P.ld;
     double* T = P.T;
 
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
     if (t == 0) s_piv = T[(size_t)r * ld + q];
     __syncthreads();
     const double piv = s_piv;
-    for (int i = t; i < P.R; i += SEL_NT)
+    for (int i = t; i < R; i += SEL_NT)
         P.pcol[i] = (i == r) ? 0.0 : T[(size_t)i * ld + q];
     __syncthreads();                                   // column read before the row is rewritten
     double* trow = T + (size_t)r * ld;
-    for (int j = t; j < P.C; j += SEL_NT) {
+    for (int j = t; j < C; j += SEL_NT) {
         double p = trow[j] / piv;
         trow[j] = p;
         P.prow[j] = p;
@@ -166,7 +167,7 @@ __device__ __forceinline__ int rule_decode(const ScanRule& R, const MinIdx& m)
 // Slow path (once per solve, or after a skipped forced pivot): pick the next column from T as it
 // stands and gather it plus the RHS column with strided reads.
 template <int NT = SEL_NT>
-__device__ int la_prepare_from_T(const SelParams& P, double* buf, int scanrow, const ScanRule& rule,
+__device__ int la_prepare_from_T(const SelParams& P, int R, int C, double* buf, int scanrow, const ScanRule& rule,
                                  double* s_v, int* s_i)
 {
     const size_t ld = (size_t)P.ld;
@@ -174,13 +175,13 @@ __device__ int la_prepare_from_T(const SelParams& P, double* buf, int scanrow, c
     if (scanrow >= 0) {
         MinIdx b; rule_init(rule, b);
         const double* srow = P.T + (size_t)scanrow * ld;
-        for (int j = threadIdx.x; j < P.C; j += NT) rule_feed(rule, b, j, srow[j]);
+        for (int j = threadIdx.x; j < C; j += NT) rule_feed(rule, b, j, srow[j]);
         b = block_min_idx<NT>(b, s_v, s_i);
         qn = rule_decode(rule, b);
     }
-    for (int i = threadIdx.x; i < P.R; i += NT) {
+    for (int i = threadIdx.x; i < R; i += NT) {
         if (qn >= 0) buf[i] = P.T[(size_t)i * ld + qn];
-        P.rhsbuf[i] = P.T[(size_t)i * ld + (P.C - 1)];
+        P.rhsbuf[i] = P.T[(size_t)i * ld + (C - 1)];
     }
     return qn;
 }
@@ -192,16 +193,17 @@ __global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P)
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int iter = st->iter;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
     double* colc = (iter & 1) ? P.col1 : P.col0;
     ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
-    rule.C = P.C; rule.c0 = 0;
-    int scanrow = P.R - 1;
+    rule.C = C; rule.c0 = 0;
+    int scanrow = R - 1;
     if (rule.forced) {
         const int k = st->forced_k;
         scanrow = k < P.fcount ? P.frows[k] : -1;
         rule.c0 = k < P.fcount ? P.fcols[k] : 0;
     }
-    int qn = la_prepare_from_T(P, colc, scanrow, rule, s_v, s_i);
+    int qn = la_prepare_from_T(P, R, C, colc, scanrow, rule, s_v, s_i);
     if (threadIdx.x == 0) {
         st->qn = qn;
         if (P.us) { *P.us = *st; P.us->qn = qn; }
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
     LPX_STAMP(0);
 
     const int t = threadIdx.x;
-    const int m = P.R - 1;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    const int m = R - 1;
     const size_t ld = (size_t)P.ld;
     double* T = P.T;
     const int iter = st->iter;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
     int r = -1, scanrow = -1;
     int final_status = LPX_RUNNING;
     ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
-    rule.C = P.C; rule.c0 = 0;
+    rule.C = C; rule.c0 = 0;
 
     if (rule.forced) {
         const int k = st->forced_k;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
             rule.c0 = (k + 1 < P.fcount) ? P.fcols[k + 1] : 0;
             if (t == 0) { P.fchosen[k] = q; st->forced_k = k + 1; }
             if (q < 0) {                                  // no eligible column: skip this pivot
-                int qn = la_prepare_from_T(P, colc, scanrow, rule, s_v, s_i);
+                int qn = la_prepare_from_T(P, R, C, colc, scanrow, rule, s_v, s_i);
                 if (t == 0) { st->r = -1; st->q = -1; st->qn = qn; }
                 return;
             }
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
     double* trow = T + (size_t)r * ld;
     const double* srow = T + (size_t)(scanrow >= 0 ? scanrow : 0) * ld;
     MinIdx best; rule_init(rule, best);
-    for (int j = t; j < P.C; j += SEL_NT) {
+    for (int j = t; j < C; j += SEL_NT) {
         const double p = trow[j] / piv;
         trow[j] = p;
         P.prow[j] = p;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
     const int qn = (scanrow >= 0) ? rule_decode(rule, best) : -1;
     if (t == 0) {
         if (qn >= 0) coln[r] = P.prow[qn];                    // row r is not touched by lpx_update
-        P.rhsbuf[r] = P.prow[P.C - 1];
+        P.rhsbuf[r] = P.prow[C - 1];
         if (!rule.forced) P.basis[r] = q;                     // basis[leaving] = entering, :110
         if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
         st->iter = iter + 1;
@@ -310,7 +313,8 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
 static constexpr int UPD_NT = 256;
 static constexpr int UPD_ROWS = 8;
 
-__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int R, int C,
+__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int Rcap, int Ccap,
+                                                     const int32_t* __restrict__ shape,
                                                      const double* __restrict__ prow,
                                                      double* fac0, double* fac1,
                                                      double* __restrict__ rhsbuf,
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
     if (st->status != LPX_RUNNING) return;
     const int r = st->r;
     if (r < 0) return;
+    const int R = shape ? shape[0] : Rcap, C = shape ? shape[1] : Ccap;
     const int par = (st->iter - 1) & 1;                   // parity of the pivot being applied
     const double* __restrict__ fac = par ? fac1 : fac0;   // pivot column snapshot (factors)
     double* __restrict__ nxt = par ? fac0 : fac1;         // by-product: next pivot's column
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
     if (col >= ld) return;                      // ld is a multiple of 16, so col+1 < ld too
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
     const int row0 = rb * UPD_ROWS;
+    if (row0 >= R) return;
     double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);              // this lane owns column qn
     const bool wr = (rhsbuf != nullptr) && (((C - 1) & ~1) == col);   // this lane owns the RHS column
@@ -393,7 +399,8 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
     if (status_in != LPX_RUNNING) { if (b == 0 && t == 0) st->status = status_in; return; }
 
     LPX_STAMP_MB(0);
-    const int m = P.R - 1;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    const int m = R - 1;
     const size_t ld = (size_t)P.ld;
     double* T = P.T;
     const int iter = us->iter;
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
     int r = -1, scanrow = -1;
     int final_status = LPX_RUNNING;
     ScanRule rule; rule.forced = (P.mode == MODE_FORCED); rule.eps = P.eps; rule.thresh = P.fthresh;
-    rule.C = P.C; rule.c0 = 0;
+    rule.C = C; rule.c0 = 0;
     const int k = us->forced_k;
 
     if (rule.forced) {
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
             rule.c0 = (k + 1 < P.fcount) ? P.fcols[k + 1] : 0;
             if (q < 0) {                                  // no eligible column: skip this pivot
                 if (b != 0) return;
-                int qn = la_prepare_from_T<MB_NT>(P, colc, scanrow, rule, s_v, s_i);
+                int qn = la_prepare_from_T<MB_NT>(P, R, C, colc, scanrow, rule, s_v, s_i);
                 if (t == 0) {
                     P.fchosen[k] = -1;
                     st->status = LPX_RUNNING; st->iter = iter; st->r = -1; st->q = -1;
@@ -442,8 +449,8 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
     }
 
     // this workgroup's column slice
-    const int per = (P.C + P.nblk - 1) / P.nblk;
-    const int j0 = b * per, j1 = min(P.C, j0 + per);
+    const int per = (C + P.nblk - 1) / P.nblk;
+    const int j0 = b * per, j1 = min(C, j0 + per);
     const double piv = colc[r];
     const bool same = (scanrow == r);
     const double fs = (scanrow >= 0 && !same) ? colc[scanrow] : 0.0;
@@ -481,7 +488,8 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
 
 // lpx_update for the multi-workgroup protocol: same streaming body; the next entering column comes from
 // the select workgroups' partials, and workgroup 0 commits the state record `us` for the next select.
-__global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, int ld, int R, int C,
+__global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, int ld, int Rcap, int Ccap,
+                                                        const int32_t* __restrict__ shape,
                                                         const double* __restrict__ prow,
                                                         double* fac0, double* fac1,
                                                         double* __restrict__ rhsbuf,
@@ -493,6 +501,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, 
     const int status = st->status;
     const int r = st->r;
     const int lane = threadIdx.x & 63;
+    const int R = shape ? shape[0] : Rcap, C = shape ? shape[1] : Ccap;
     if (status != LPX_RUNNING) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { us->status = status; us->iter = st->iter; }
         return;
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, 
     if (col >= ld) return;
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
     const int row0 = rb * UPD_ROWS;
+    if (row0 >= R) return;                                // capacity-sized grid: rows beyond the live shape
     double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);
     const bool wr = (((C - 1) & ~1) == col);
@@ -558,6 +568,49 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, 
             if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Branch-and-bound node assembly on the device.  A node LP is the root model plus `d` unit rows
+// (Models/Branch&Bound.cs:233-248); its tableau (BuildTableau, Models/PrimalSimplex.cs:179-203) is the
+// root tableau with d more rows and d more slack columns.  The root tableau stays resident; a node is
+// built by one streaming kernel from it and d cut descriptors instead of 8 MB of host work + H2D.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lpx_build_node(const double* __restrict__ T0, int ld0, int R0, int C0,
+                                                      double* __restrict__ T, int ld, int R, int C,
+                                                      const int32_t* __restrict__ cvar, const double* __restrict__ ccoef,
+                                                      const double* __restrict__ czero, const double* __restrict__ crhs,
+                                                      int32_t* __restrict__ basis)
+{
+    const int m0 = R0 - 1, m = R - 1, n = C0 - R0, d = R - R0;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j == 0 && i < m) basis[i] = n + i;                               // :197
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < C) {
+        if (i < m0 || i == m) {                                          // root constraint rows / objective row
+            const int i0 = (i == m) ? m0 : i;
+            if (j < n + m0) v = T0[(size_t)i0 * ld0 + j];
+            else if (j == C - 1) v = T0[(size_t)i0 * ld0 + (C0 - 1)];
+        } else {                                                         // branching row k
+            const int k = i - m0;
+            if (j < n) v = (j == cvar[k]) ? ccoef[k] : czero[k];
+            else if (j == n + m0 + k) v = 1.0;                           // its slack, :191
+            else if (j == C - 1) v = crhs[k];                            // :192
+        }
+    }
+    (void)d;
+    T[(size_t)i * ld + j] = v;
+}
+
+hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,
+                             const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
+                             int32_t* basis, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_build_node, dim3((ld + 255) / 256, R), dim3(256), 0, s, T0, ld0, R0, C0, T, ld, R, C,
+                       cvar, ccoef, czero, crhs, basis);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -599,11 +652,11 @@ hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hi
     const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
     const int forced = p.mode == MODE_FORCED ? 1 : 0;
     if (e0 && e1)
-        hipExtLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C,
+        hipExtLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
                               (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     else
-        hipLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, p.T, p.ld, p.R, p.C,
+        hipLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, p.T, p.ld, p.R, p.C, p.shape,
                            (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
                            (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     return hipGetLastError();
@@ -615,7 +668,7 @@ hipError_t launch_la_init(const SelParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, double* fac0, double* fac1,
+hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, const double* prow, double* fac0, double* fac1,
                          double* rhsbuf, const DevState* st, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     const int ncw = (ld + 127) / 128;
@@ -624,10 +677,10 @@ hipError_t launch_update(double* T, int ld, int R, int C, const double* prow, do
     const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
     if (e0 && e1)
         hipExtLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0,
-                              T, ld, R, C, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+                              T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
     else
         hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s,
-                           T, ld, R, C, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+                           T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -120,11 +121,110 @@ __global__ __launch_bounds__(KN_NT) void knap_relax_batch(KnParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prefix-sum form (all weights >= 0): one WAVE per node, O(depth * log n) instead of O(n).
+// PW[s] / PP[s] are the running sums of weights / profits over the ratio-ordered items [0, s), built
+// once on the host with the reference's left-to-right additions.  For a node with fixed set F the
+// undecided weight in front of position t is U(t) = PW[t] - sum_{f in F, pos_f < t} w_f, non-decreasing
+// in t, so the reference's greedy (`weight + w_i <= cap + EPS` until the first failure, :468-487) stops
+// at j = t* - 1 with t* the smallest t in [1, n] such that W1 + U(t) > cap + EPS -- a binary search
+// whose every probe is one wave reduction over the node's fixed entries.  j is undecided by minimality
+// (a fixed j would give U(t*) == U(t* - 1)).  Sums are exact and order-free for integer data below 2^53
+// (the synthetic configuration); other data is reproduced to 1e-9 relative only, as the scan kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double x)
+{
+    x += dpp_f64<0x111, 0xf>(0.0, x);
+    x += dpp_f64<0x112, 0xf>(0.0, x);
+    x += dpp_f64<0x114, 0xf>(0.0, x);
+    x += dpp_f64<0x118, 0xf>(0.0, x);
+    x += dpp_f64<0x142, 0xa>(0.0, x);
+    x += dpp_f64<0x143, 0xc>(0.0, x);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+struct KnPrefix { const double* PW; const double* PP; };
+
+static constexpr int KP_CACHE = 4;        // fixed entries cached in registers per lane (depth <= 256)
+
+__global__ __launch_bounds__(256) void knap_relax_prefix(KnParams P, KnPrefix X)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int node = blockIdx.x * 4 + wave;
+    if (node >= P.count) return;
+    const int n = P.n;
+    const int f0 = P.off[node], d = P.off[node + 1] - f0;
+    int cpos[KP_CACHE]; double cw[KP_CACHE], cp[KP_CACHE];
+    double w1 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KP_CACHE; ++k) {
+        const int e = lane + 64 * k;
+        cpos[k] = INT_MAX; cw[k] = 0.0; cp[k] = 0.0;
+        if (e < d) {
+            const int i = P.fidx[f0 + e];
+            cpos[k] = P.pos[i]; cw[k] = P.w0[i]; cp[k] = P.p0[i];
+            if (P.fval[f0 + e] == 1) { w1 += cw[k]; p1 += cp[k]; }
+        }
+    }
+    for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {            // deeper nodes: the tail stays in memory
+        const int i = P.fidx[f0 + e];
+        if (P.fval[f0 + e] == 1) { w1 += P.w0[i]; p1 += P.p0[i]; }
+    }
+    const double W1 = wave_sum_f64(w1), P1 = wave_sum_f64(p1);     // :442-452 (exact for integer data)
+    if (W1 > P.cap + KEPS) {                                        // :455-456
+        if (lane == 0) { P.out_profit[node] = P1; P.out_weight[node] = W1; P.out_frac[node] = -1; P.out_fracval[node] = 0.0; }
+        return;
+    }
+    // fixed weight / profit in front of position t
+    auto fixed_before = [&](int t, double& fw, double& fp) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP_CACHE; ++k) if (cpos[k] < t) { a += cw[k]; b += cp[k]; }
+        for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {
+            const int i = P.fidx[f0 + e];
+            if (P.pos[i] < t) { a += P.w0[i]; b += P.p0[i]; }
+        }
+        fw = wave_sum_f64(a); fp = wave_sum_f64(b);
+    };
+    int lo = 1, hi = n + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        double fw, fp;
+        fixed_before(mid, fw, fp);
+        if (W1 + (X.PW[mid] - fw) > P.cap + KEPS) hi = mid; else lo = mid + 1;
+    }
+    double fw, fp;
+    if (lo == n + 1) {                                              // everything undecided fits
+        fixed_before(n, fw, fp);
+        if (lane == 0) {
+            P.out_profit[node] = P1 + (X.PP[n] - fp); P.out_weight[node] = W1 + (X.PW[n] - fw);
+            P.out_frac[node] = -1; P.out_fracval[node] = 0.0;
+        }
+        return;
+    }
+    const int j = lo - 1;                                           // first undecided item that does not fit
+    fixed_before(j, fw, fp);
+    double w = W1 + (X.PW[j] - fw), p = P1 + (X.PP[j] - fp);
+    int frac = -1; double fv = 0.0;
+    const double wi = P.ws[j];
+    const double remain = P.cap - w;
+    if (remain > KEPS && wi > KEPS) {                               // :476-484
+        fv = remain / wi;
+        p += P.ps[j] * fv;
+        w += wi * fv;
+        frac = j;
+    }
+    if (lane == 0) { P.out_profit[node] = p; P.out_weight[node] = w; P.out_frac[node] = frac; P.out_fracval[node] = fv; }
+}
+
 }  // namespace lpx
 
 using namespace lpx;
 
 struct lpx_knapsack {
+    double *PW = nullptr, *PP = nullptr; bool prefix_ok = false;
     int n = 0; double cap = 0;
     double *ws = nullptr, *ps = nullptr, *w0 = nullptr, *p0 = nullptr;
     int32_t* pos = nullptr;
@@ -133,6 +233,9 @@ struct lpx_knapsack {
     int cap_nodes = 0, cap_fix = 0;
     int32_t *d_off = nullptr, *d_fidx = nullptr, *d_frac = nullptr; int8_t* d_fval = nullptr;
     double *d_profit = nullptr, *d_weight = nullptr, *d_fracval = nullptr;
+    // pinned staging so that a batch is one H2D + one D2H instead of seven pageable copies
+    char* d_in = nullptr; char* h_in = nullptr; size_t in_cap = 0;
+    char* d_out = nullptr; char* h_out = nullptr; size_t out_cap = 0;
     hipStream_t stream = nullptr;
 };
 
@@ -142,9 +245,12 @@ void lpx_knapsack_destroy(lpx_knapsack* k)
 {
     if (!k) return;
     if (k->stream) hipStreamSynchronize(k->stream);
-    hipFree(k->ws); hipFree(k->ps); hipFree(k->w0); hipFree(k->p0); hipFree(k->pos);
+    hipFree(k->ws); hipFree(k->ps); hipFree(k->w0); hipFree(k->p0); hipFree(k->pos); hipFree(k->PW); hipFree(k->PP);
     hipFree(k->d_off); hipFree(k->d_fidx); hipFree(k->d_frac); hipFree(k->d_fval);
     hipFree(k->d_profit); hipFree(k->d_weight); hipFree(k->d_fracval);
+    hipFree(k->d_in); hipFree(k->d_out);
+    if (k->h_in) hipHostFree(k->h_in);
+    if (k->h_out) hipHostFree(k->h_out);
     if (k->stream) hipStreamDestroy(k->stream);
     delete k;
 }
@@ -183,6 +289,12 @@ int lpx_knapsack_create(const double* profit, const double* weight, int n, doubl
     up((void**)&k->ws, ws.data(), sizeof(double) * n); up((void**)&k->ps, ps.data(), sizeof(double) * n);
     up((void**)&k->w0, weight, sizeof(double) * n); up((void**)&k->p0, profit, sizeof(double) * n);
     up((void**)&k->pos, pos.data(), sizeof(int32_t) * n);
+    // running sums in ratio order (left-to-right, as the reference accumulates) for the prefix-sum kernel
+    std::vector<double> PW(n + 1, 0.0), PP(n + 1, 0.0);
+    bool nonneg = true;
+    for (int s = 0; s < n; ++s) { PW[s + 1] = PW[s] + ws[s]; PP[s + 1] = PP[s] + ps[s]; if (!(ws[s] >= 0.0)) nonneg = false; }
+    k->prefix_ok = nonneg;
+    up((void**)&k->PW, PW.data(), sizeof(double) * (n + 1)); up((void**)&k->PP, PP.data(), sizeof(double) * (n + 1));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error(std::string("lpx_knapsack_create: ") + hipGetErrorString(e)); lpx_knapsack_destroy(k); return LPX_EDEVICE; }
     *out = k;
@@ -205,41 +317,54 @@ int lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, con
     const int nfix = off[count];
     for (int e = 0; e < nfix; ++e)
         if (fix_idx[e] < 0 || fix_idx[e] >= k->n) { set_error("lpx_knapsack_relax_batch: fixed index outside [0,n)"); return LPX_EINVAL; }
-    if (count > k->cap_nodes) {
-        hipFree(k->d_off); hipFree(k->d_frac); hipFree(k->d_profit); hipFree(k->d_weight); hipFree(k->d_fracval);
-        int c = std::max(count, 2 * k->cap_nodes);
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_off, sizeof(int32_t) * (c + 1)));
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_frac, sizeof(int32_t) * c));
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_profit, sizeof(double) * c));
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_weight, sizeof(double) * c));
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_fracval, sizeof(double) * c));
-        k->cap_nodes = c;
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_off = 0, o_fidx = up8(sizeof(int32_t) * (count + 1)), o_fval = o_fidx + up8(sizeof(int32_t) * (size_t)(nfix > 0 ? nfix : 1));
+    const size_t in_bytes = o_fval + up8((size_t)(nfix > 0 ? nfix : 1));
+    const size_t o_p = 0, o_w = sizeof(double) * count, o_fv = 2 * sizeof(double) * count, o_fr = 3 * sizeof(double) * count;
+    const size_t out_bytes = o_fr + up8(sizeof(int32_t) * count);
+    if (in_bytes > k->in_cap) {
+        hipFree(k->d_in); if (k->h_in) hipHostFree(k->h_in);
+        k->d_in = nullptr; k->h_in = nullptr; k->in_cap = 0;
+        const size_t c = std::max(in_bytes, 2 * k->in_cap) + 4096;
+        LPX_HIP_TRY(hipMalloc((void**)&k->d_in, c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&k->h_in, c));
+        k->in_cap = c;
     }
-    if (nfix > k->cap_fix) {
-        hipFree(k->d_fidx); hipFree(k->d_fval);
-        int c = std::max(nfix, 2 * k->cap_fix);
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_fidx, sizeof(int32_t) * c));
-        LPX_HIP_TRY(hipMalloc((void**)&k->d_fval, c));
-        k->cap_fix = c;
+    if (out_bytes > k->out_cap) {
+        hipFree(k->d_out); if (k->h_out) hipHostFree(k->h_out);
+        k->d_out = nullptr; k->h_out = nullptr; k->out_cap = 0;
+        const size_t c = std::max(out_bytes, 2 * k->out_cap) + 4096;
+        LPX_HIP_TRY(hipMalloc((void**)&k->d_out, c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&k->h_out, c));
+        k->out_cap = c;
     }
+    std::memcpy(k->h_in + o_off, off, sizeof(int32_t) * (count + 1));
+    if (nfix > 0) { std::memcpy(k->h_in + o_fidx, fix_idx, sizeof(int32_t) * nfix); std::memcpy(k->h_in + o_fval, fix_val, nfix); }
     hipStream_t s = k->stream;
-    LPX_HIP_TRY(hipMemcpyAsync(k->d_off, off, sizeof(int32_t) * (count + 1), hipMemcpyHostToDevice, s));
-    if (nfix > 0) {
-        LPX_HIP_TRY(hipMemcpyAsync(k->d_fidx, fix_idx, sizeof(int32_t) * nfix, hipMemcpyHostToDevice, s));
-        LPX_HIP_TRY(hipMemcpyAsync(k->d_fval, fix_val, nfix, hipMemcpyHostToDevice, s));
-    }
+    LPX_HIP_TRY(hipMemcpyAsync(k->d_in, k->h_in, in_bytes, hipMemcpyHostToDevice, s));
     KnParams P;
     P.n = k->n; P.cap = k->cap; P.ws = k->ws; P.ps = k->ps; P.pos = k->pos; P.w0 = k->w0; P.p0 = k->p0;
-    P.count = count; P.off = k->d_off; P.fidx = k->d_fidx; P.fval = k->d_fval;
-    P.out_profit = k->d_profit; P.out_weight = k->d_weight; P.out_frac = k->d_frac; P.out_fracval = k->d_fracval;
-    const size_t dyn = sizeof(unsigned int) * ((k->n + 31) / 32);
-    hipLaunchKernelGGL(knap_relax_batch, dim3(count), dim3(KN_NT), dyn, s, P);
+    P.count = count;
+    P.off = reinterpret_cast<const int32_t*>(k->d_in + o_off);
+    P.fidx = reinterpret_cast<const int32_t*>(k->d_in + o_fidx);
+    P.fval = reinterpret_cast<const int8_t*>(k->d_in + o_fval);
+    P.out_profit = reinterpret_cast<double*>(k->d_out + o_p); P.out_weight = reinterpret_cast<double*>(k->d_out + o_w);
+    P.out_fracval = reinterpret_cast<double*>(k->d_out + o_fv); P.out_frac = reinterpret_cast<int32_t*>(k->d_out + o_fr);
+    static const bool force_scan = [] { const char* e = std::getenv("LPX_KNAP_SCAN"); return e && e[0] == '1'; }();
+    if (k->prefix_ok && !force_scan) {
+        KnPrefix X; X.PW = k->PW; X.PP = k->PP;
+        hipLaunchKernelGGL(knap_relax_prefix, dim3((count + 3) / 4), dim3(256), 0, s, P, X);
+    } else {
+        const size_t dyn = sizeof(unsigned int) * ((k->n + 31) / 32);
+        hipLaunchKernelGGL(knap_relax_batch, dim3(count), dim3(KN_NT), dyn, s, P);
+    }
     LPX_HIP_TRY(hipGetLastError());
-    if (profit) LPX_HIP_TRY(hipMemcpyAsync(profit, k->d_profit, sizeof(double) * count, hipMemcpyDeviceToHost, s));
-    if (weight) LPX_HIP_TRY(hipMemcpyAsync(weight, k->d_weight, sizeof(double) * count, hipMemcpyDeviceToHost, s));
-    if (frac_idx) LPX_HIP_TRY(hipMemcpyAsync(frac_idx, k->d_frac, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
-    if (frac_val) LPX_HIP_TRY(hipMemcpyAsync(frac_val, k->d_fracval, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    LPX_HIP_TRY(hipMemcpyAsync(k->h_out, k->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     LPX_HIP_TRY(hipStreamSynchronize(s));
+    if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * count);
+    if (weight) std::memcpy(weight, k->h_out + o_w, sizeof(double) * count);
+    if (frac_val) std::memcpy(frac_val, k->h_out + o_fv, sizeof(double) * count);
+    if (frac_idx) std::memcpy(frac_idx, k->h_out + o_fr, sizeof(int32_t) * count);
     return 0;
 }
 

@@ -235,7 +235,7 @@ static int rv_enqueue(lpx_revised* r, const RvParams& p, hipStream_t s, hipEvent
     hipLaunchKernelGGL(rv_ftran, dim3((p.m + 3) / 4), dim3(256), 0, s, p);
     hipLaunchKernelGGL(rv_select, dim3(1), dim3(SEL_NT), 0, s, p);
     LPX_HIP_TRY(hipGetLastError());
-    LPX_HIP_TRY(launch_update(p.W, p.ldw, p.m + 1, p.m + 1, p.prow, p.fac, p.fac, p.rhsbuf, p.st, s, e0, e1));
+    LPX_HIP_TRY(launch_update(p.W, p.ldw, p.m + 1, p.m + 1, nullptr, p.prow, p.fac, p.fac, p.rhsbuf, p.st, s, e0, e1));
     return 0;
 }
 

@@ -11,7 +11,10 @@ namespace lpx { const std::string& get_error(); extern int g_device; }
 using namespace lpx;
 
 struct lpx_tableau {
-    int R = 0, C = 0, ld = 0;
+    int R = 0, C = 0, ld = 0;   // live shape (<= capacity) and leading dimension (from the capacity)
+    int Rcap = 0, Ccap = 0;
+    int32_t* shape = nullptr;   // device record {R, C} read by the kernels
+    int32_t* shape_h = nullptr; // pinned staging
     double* T = nullptr;        // [R*ld]
     double* snapT = nullptr;    // snapshot
     double* prow = nullptr;     // [ld]
@@ -30,6 +33,7 @@ struct lpx_tableau {
     DevState* st = nullptr;     // device
     DevState* hst = nullptr;    // pinned host mirror
     int32_t* frows = nullptr; int32_t* fcols = nullptr; int32_t* fchosen = nullptr; int fcap = 0;
+    char* cutbuf = nullptr; char* cutbuf_h = nullptr; int cutcap = 0;   // staging of branching-row descriptors
     hipStream_t stream = nullptr;
     // cached graph of `g_batch` (select, update) pairs
     hipGraphExec_t gexec = nullptr;
@@ -91,7 +95,8 @@ void lpx_default_opts(lpx_run_opts* o, int dual)
     o->fdf_guard = 100;
     o->cleanup = 0;
     o->batch = 0;
-    o->use_graph = 1;
+    static const bool no_graph = [] { const char* e = std::getenv("LPX_GRAPH"); return e && e[0] == '0'; }();
+    o->use_graph = no_graph ? 0 : 1;     // LPX_GRAPH=0: diagnostic switch to eager launches
     o->profile = 0;
 }
 
@@ -101,7 +106,7 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     int rc = ensure_device();
     if (rc) return rc;
     lpx_tableau* t = new lpx_tableau();
-    t->R = R; t->C = C; t->ld = (C + 15) / 16 * 16;
+    t->R = R; t->C = C; t->Rcap = R; t->Ccap = C; t->ld = (C + 15) / 16 * 16;
     const size_t tb = sizeof(double) * (size_t)R * t->ld;
     const int wsn = R > C ? R : C;
     t->trace_cap = 1 << 16;
@@ -127,13 +132,17 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     ALLOC(t->basis, sizeof(int32_t) * (R > 1 ? R - 1 : 1));
     ALLOC(t->trace, sizeof(int32_t) * 2 * t->trace_cap);
     ALLOC(t->st, sizeof(DevState));
+    ALLOC(t->shape, sizeof(int32_t) * 2);
 #undef ALLOC
     if (hipHostMalloc((void**)&t->hst, sizeof(DevState)) != hipSuccess ||
+        hipHostMalloc((void**)&t->shape_h, sizeof(int32_t) * 2) != hipSuccess ||
         hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("host-pinned state / stream creation failed");
         lpx_tableau_destroy(t);
         return LPX_EDEVICE;
     }
+    t->shape_h[0] = R; t->shape_h[1] = C;
+    hipMemcpyAsync(t->shape, t->shape_h, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream);
     hipMemsetAsync(t->T, 0, tb, t->stream);
     hipMemsetAsync(t->prow, 0, sizeof(double) * t->ld, t->stream);
     hipMemsetAsync(t->pcol, 0, sizeof(double) * R, t->stream);
@@ -155,7 +164,9 @@ void lpx_tableau_destroy(lpx_tableau* t)
     for (hipEvent_t e : t->events) hipEventDestroy(e);
     hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws); hipFree(t->part_v); hipFree(t->part_i); hipFree(t->us);
     hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
-    hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen);
+    hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf); hipFree(t->shape);
+    if (t->shape_h) hipHostFree(t->shape_h);
+    if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
     if (t->hst) hipHostFree(t->hst);
     if (t->stream) hipStreamDestroy(t->stream);
     delete t;
@@ -265,13 +276,13 @@ int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e
 {
     if (p.mode == MODE_DUAL) {
         LPX_HIP_TRY(launch_select(p, s));
-        LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->pcol, t->pcol, nullptr, t->st, s, e0, e1));
+        LPX_HIP_TRY(launch_update(t->T, t->ld, t->Rcap, t->Ccap, t->shape, t->prow, t->pcol, t->pcol, nullptr, t->st, s, e0, e1));
     } else if (p.us) {
         LPX_HIP_TRY(launch_select_mb(p, s));
         LPX_HIP_TRY(launch_update_mb(p, s, e0, e1));
     } else {
         LPX_HIP_TRY(launch_select_la(p, s));
-        LPX_HIP_TRY(launch_update(t->T, t->ld, t->R, t->C, t->prow, t->col0, t->col1, t->rhsbuf, t->st, s, e0, e1));
+        LPX_HIP_TRY(launch_update(t->T, t->ld, t->Rcap, t->Ccap, t->shape, t->prow, t->col0, t->col1, t->rhsbuf, t->st, s, e0, e1));
     }
     return 0;
 }
@@ -302,7 +313,7 @@ int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budge
 SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
 {
     SelParams p; std::memset(&p, 0, sizeof(p));
-    p.T = t->T; p.ld = t->ld; p.R = t->R; p.C = t->C;
+    p.T = t->T; p.ld = t->ld; p.R = t->Rcap; p.C = t->Ccap; p.shape = t->shape;
     p.prow = t->prow; p.pcol = t->pcol; p.col0 = t->col0; p.col1 = t->col1; p.rhsbuf = t->rhsbuf; p.basis = t->basis; p.trace = t->trace; p.trace_cap = t->trace_cap;
     p.st = t->st;
     p.eps = o->eps;
@@ -313,7 +324,7 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
     p.rcap = 0;
     static const bool mb_env = [] { const char* e = std::getenv("LPX_SELECT_MB"); return !(e && e[0] == '0'); }();
     if (mode != MODE_DUAL && mb_env && t->use_mb) {
-        p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->C);
+        p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->Ccap);
     }
     return p;
 }
@@ -393,6 +404,48 @@ static int one_shot(double* T, int R, int C, int32_t* basis, const lpx_run_opts*
     lpx_tableau_destroy(t);
     if (st) *st = local;
     return rc ? rc : status;
+}
+
+int lpx_tableau_set_shape(lpx_tableau* t, int R, int C)
+{
+    if (!t || R < 1 || C < 2 || R > t->Rcap || C > t->Ccap) { set_error("lpx_tableau_set_shape: shape outside the handle's capacity"); return LPX_EINVAL; }
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));          // the pinned staging word may still be in flight
+    t->R = R; t->C = C;
+    t->shape_h[0] = R; t->shape_h[1] = C;
+    LPX_HIP_TRY(hipMemcpyAsync(t->shape, t->shape_h, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    return 0;
+}
+
+int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts, const int32_t* var,
+                           const double* coef, const double* zero, const double* rhs)
+{
+    if (!node || !root || ncuts < 0 || (ncuts > 0 && (!var || !coef || !zero || !rhs))) { set_error("lpx_tableau_build_node: bad argument"); return LPX_EINVAL; }
+    if (root->R + ncuts > node->Rcap || root->C + ncuts > node->Ccap) { set_error("lpx_tableau_build_node: root shape + ncuts exceeds the node handle's capacity"); return LPX_EINVAL; }
+    { int rc = lpx_tableau_set_shape(node, root->R + ncuts, root->C + ncuts); if (rc) return rc; }
+    const int n = root->C - root->R;
+    for (int k = 0; k < ncuts; ++k) if (var[k] < 0 || var[k] >= n) { set_error("lpx_tableau_build_node: branching variable out of range"); return LPX_EINVAL; }
+    const int need = ncuts > 0 ? ncuts : 1;
+    if (need > node->cutcap) {
+        hipFree(node->cutbuf); if (node->cutbuf_h) hipHostFree(node->cutbuf_h);
+        node->cutbuf = nullptr; node->cutbuf_h = nullptr; node->cutcap = 0;
+        const int c = need + 64;
+        LPX_HIP_TRY(hipMalloc((void**)&node->cutbuf, (size_t)c * 32));
+        LPX_HIP_TRY(hipHostMalloc((void**)&node->cutbuf_h, (size_t)c * 32));
+        node->cutcap = c;
+    }
+    const size_t cap = (size_t)node->cutcap;
+    double* hc = reinterpret_cast<double*>(node->cutbuf_h);          // [coef | zero | rhs | var(int32, padded)]
+    for (int k = 0; k < ncuts; ++k) { hc[k] = coef[k]; hc[cap + k] = zero[k]; hc[2 * cap + k] = rhs[k]; }
+    int32_t* hv = reinterpret_cast<int32_t*>(hc + 3 * cap);
+    for (int k = 0; k < ncuts; ++k) hv[k] = var[k];
+    LPX_HIP_TRY(hipMemcpyAsync(node->cutbuf, node->cutbuf_h, cap * 32, hipMemcpyHostToDevice, node->stream));
+    const double* dc = reinterpret_cast<const double*>(node->cutbuf);
+    const double* T0 = root->snapT ? root->snapT : root->T;          // the pristine root tableau
+    LPX_HIP_TRY(launch_build_node(T0, root->ld, root->R, root->C, node->T, node->ld, node->R, node->C,
+                                  reinterpret_cast<const int32_t*>(dc + 3 * cap), dc, dc + cap, dc + 2 * cap,
+                                  node->basis, node->stream));
+    LPX_HIP_TRY(hipMemsetAsync(node->st, 0, sizeof(DevState), node->stream));
+    return 0;   // stream-ordered: the run that follows on node->stream sees the finished tableau
 }
 
 int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z)
