@@ -64,6 +64,9 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
 hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int select_mb_blocks(int C);
+hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s);
+hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s);
+int update_blocks(int ld, int R);
 hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,
                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
                              int32_t* basis, hipStream_t s);

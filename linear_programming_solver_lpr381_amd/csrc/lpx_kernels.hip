@@ -15,7 +15,7 @@ namespace lpx {
 // ------------------------------------------------------------------------------------------------
 // lpx_select: one workgroup decides the next pivot and prepares the update's operands.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P)
+__device__ __forceinline__ void lpx_select_body(const SelParams& P)
 {
     __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
@@ -186,7 +186,7 @@ __device__ int la_prepare_from_T(const SelParams& P, int R, int C, double* buf, 
     return qn;
 }
 
-__global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P)
+__device__ __forceinline__ void lpx_la_init_body(const SelParams& P)
 {
     __shared__ double s_v[SEL_NW];
     __shared__ int s_i[SEL_NW];
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
 static constexpr int UPD_NT = 256;
 static constexpr int UPD_ROWS = 8;
 
-__global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int ld, int Rcap, int Ccap,
-                                                     const int32_t* __restrict__ shape,
-                                                     const double* __restrict__ prow,
-                                                     double* fac0, double* fac1,
-                                                     double* __restrict__ rhsbuf,
-                                                     const DevState* __restrict__ st,
-                                                     int ncw, int nunits)
+__device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
+                                                const int32_t* __restrict__ shape,
+                                                const double* __restrict__ prow,
+                                                double* fac0, double* fac1,
+                                                double* __restrict__ rhsbuf,
+                                                const DevState* __restrict__ st,
+                                                int ncw, int nunits)
 {
     if (st->status != LPX_RUNNING) return;
     const int r = st->r;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update(double* __restrict__ T, int
 // Nothing is read and written by workgroups of the same launch, so no inter-workgroup fence is needed;
 // the kernel boundary orders the rest (placement-independent, cdna_hip_programming.md G16).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
+__device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
 {
     __shared__ int s_out;
     __shared__ double s_v[MB_NT / 64];
@@ -488,15 +488,15 @@ __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P)
 
 // lpx_update for the multi-workgroup protocol: same streaming body; the next entering column comes from
 // the select workgroups' partials, and workgroup 0 commits the state record `us` for the next select.
-__global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, int ld, int Rcap, int Ccap,
-                                                        const int32_t* __restrict__ shape,
-                                                        const double* __restrict__ prow,
-                                                        double* fac0, double* fac1,
-                                                        double* __restrict__ rhsbuf,
-                                                        const DevState* __restrict__ st, DevState* us,
-                                                        const double* __restrict__ part_v,
-                                                        const int32_t* __restrict__ part_i, int nblk,
-                                                        int forced, int ncw, int nunits)
+__device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
+                                                   const int32_t* __restrict__ shape,
+                                                   const double* __restrict__ prow,
+                                                   double* fac0, double* fac1,
+                                                   double* __restrict__ rhsbuf,
+                                                   const DevState* __restrict__ st, DevState* us,
+                                                   const double* __restrict__ part_v,
+                                                   const int32_t* __restrict__ part_i, int nblk,
+                                                   int forced, int ncw, int nunits)
 {
     const int status = st->status;
     const int r = st->r;
@@ -568,6 +568,47 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* __restrict__ T, 
             if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
         }
     }
+}
+
+// single-tableau and batched (blockIdx.y = node of a branch-and-bound group) entry points
+__global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P) { lpx_select_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P) { lpx_la_init_body(P); }
+__global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P) { lpx_select_mb_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_select_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_select_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_la_init_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_la_init_body(P); }
+__global__ __launch_bounds__(MB_NT) void lpx_select_mb_b(const SelParams* __restrict__ arr)
+{
+    const SelParams P = arr[blockIdx.y];
+    if ((int)blockIdx.x >= P.nblk) return;          // grid is sized for the widest node of the group
+    lpx_select_mb_body(P);
+}
+
+__global__ __launch_bounds__(UPD_NT) void lpx_update(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                     const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                     const DevState* st, int ncw, int nunits)
+{
+    lpx_update_body(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+}
+__global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                        const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                        const DevState* st, DevState* us, const double* part_v,
+                                                        const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
+{
+    lpx_update_mb_body(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+}
+// batched: every node of the group advances by one pivot per launch pair; grid.x covers the largest node
+__global__ __launch_bounds__(UPD_NT) void lpx_update_b(const SelParams* __restrict__ arr)
+{
+    const SelParams P = arr[blockIdx.y];
+    const int ncw = (P.ld + 127) / 128, nunits = ncw * ((P.R + UPD_ROWS - 1) / UPD_ROWS);
+    lpx_update_body(P.T, P.ld, P.R, P.C, P.shape, P.prow, P.pcol, P.pcol, nullptr, P.st, ncw, nunits);
+}
+__global__ __launch_bounds__(UPD_NT) void lpx_update_mb_b(const SelParams* __restrict__ arr)
+{
+    const SelParams P = arr[blockIdx.y];
+    const int ncw = (P.ld + 127) / 128, nunits = ncw * ((P.R + UPD_ROWS - 1) / UPD_ROWS);
+    lpx_update_mb_body(P.T, P.ld, P.R, P.C, P.shape, P.prow, P.col0, P.col1, P.rhsbuf, P.st, P.us, P.part_v, P.part_i,
+                       P.nblk, P.mode == MODE_FORCED ? 1 : 0, ncw, nunits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -660,6 +701,29 @@ hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hi
                            (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
                            (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     return hipGetLastError();
+}
+
+// one iteration of a whole group: `arr` holds `count` parameter records in device memory
+hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s)
+{
+    if (dual) {
+        hipLaunchKernelGGL(lpx_select_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);
+        hipLaunchKernelGGL(lpx_update_b, dim3(max_upd_blocks, count), dim3(UPD_NT), 0, s, arr);
+    } else {
+        hipLaunchKernelGGL(lpx_select_mb_b, dim3(max_nblk, count), dim3(MB_NT), 0, s, arr);
+        hipLaunchKernelGGL(lpx_update_mb_b, dim3(max_upd_blocks, count), dim3(UPD_NT), 0, s, arr);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_la_init_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);
+    return hipGetLastError();
+}
+int update_blocks(int ld, int R)
+{
+    const int nunits = ((ld + 127) / 128) * ((R + UPD_ROWS - 1) / UPD_ROWS);
+    return (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
 }
 
 hipError_t launch_la_init(const SelParams& p, hipStream_t s)

@@ -331,6 +331,143 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Batched group run (K9): all tableaux of a group advance one pivot per launch pair (blockIdx.y = node),
+// so many small node LPs fill the chip from ONE stream instead of competing for a few hardware queues.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct GroupBuf {
+    SelParams* d = nullptr; SelParams* h = nullptr; DevState* hs = nullptr; int cap = 0;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t gexec = nullptr; std::string gkey;
+};
+GroupBuf g_groups[2];        // [primal, dual]; lpx handles are used from one thread per process
+
+int group_reserve(GroupBuf& g, int count)
+{
+    if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (count <= g.cap) return 0;
+    if (g.gexec) { hipGraphExecDestroy(g.gexec); g.gexec = nullptr; g.gkey.clear(); }
+    hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
+    g.d = nullptr; g.h = nullptr; g.hs = nullptr; g.cap = 0;
+    const int c = count + 16;
+    LPX_HIP_TRY(hipMalloc((void**)&g.d, sizeof(SelParams) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(SelParams) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.hs, sizeof(DevState) * c));
+    g.cap = c;
+    return 0;
+}
+
+struct GroupRun {
+    GroupBuf* g = nullptr; std::vector<int> idx; int dual = 0; int batch = 64; long long budget = 0, enq = 0;
+    int max_nblk = 1, max_blocks = 1; bool done = true;
+};
+
+int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
+{
+    GroupBuf& g = *r.g;
+    const int K = (int)r.idx.size();
+    int rc = group_reserve(g, K); if (rc) return rc;
+    r.batch = o->batch > 0 ? o->batch : 64;
+    r.budget = r.dual ? (long long)o->fdf_guard + 2LL * o->max_iter + 8 : (long long)o->max_iter + 2;
+    r.max_nblk = 1; r.max_blocks = 1;
+    for (int k = 0; k < K; ++k) {
+        lpx_tableau* t = ts[r.idx[k]];
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));               // node assembly ran on the node's own stream
+        SelParams p = base_params(t, o, r.dual ? MODE_DUAL : MODE_PRIMAL);
+        if (!r.dual && !p.us) { set_error("batched primal run needs the multi-workgroup select"); return LPX_EINVAL; }
+        g.h[k] = p;
+        if (p.nblk > r.max_nblk) r.max_nblk = p.nblk;
+        const int ub = update_blocks(t->ld, t->Rcap);
+        if (ub > r.max_blocks) r.max_blocks = ub;
+        DevState init; std::memset(&init, 0, sizeof(init));
+        init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = r.dual ? 0 : 2;
+        g.hs[k] = init;
+        LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[k], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
+    }
+    LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(SelParams) * K, hipMemcpyHostToDevice, g.stream));
+    if (!r.dual) LPX_HIP_TRY(launch_group_init(g.d, K, g.stream));
+    // graph of `batch` iterations, keyed by everything baked into the launches
+    char keybuf[160];
+    std::snprintf(keybuf, sizeof(keybuf), "%p/%d/%d/%d/%d/%d", (void*)g.d, K, r.dual, r.max_nblk, r.max_blocks, r.batch);
+    if (o->use_graph && g.gkey != keybuf) {
+        if (g.gexec) { hipGraphExecDestroy(g.gexec); g.gexec = nullptr; }
+        LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+        hipGraph_t graph = nullptr;
+        LPX_HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < r.batch; ++i) {
+            hipError_t e = launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream);
+            if (e != hipSuccess) { hipStreamEndCapture(g.stream, &graph); if (graph) hipGraphDestroy(graph); set_error("group capture failed"); return LPX_EDEVICE; }
+        }
+        LPX_HIP_TRY(hipStreamEndCapture(g.stream, &graph));
+        hipError_t e = hipGraphInstantiate(&g.gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { g.gexec = nullptr; set_error("group graph instantiate failed"); return LPX_EDEVICE; }
+        g.gkey = keybuf;
+    }
+    r.enq = 0; r.done = false;
+    return 0;
+}
+
+int group_submit(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
+{
+    GroupBuf& g = *r.g;
+    const int K = (int)r.idx.size();
+    if (o->use_graph && g.gexec) LPX_HIP_TRY(hipGraphLaunch(g.gexec, g.stream));
+    else for (int i = 0; i < r.batch; ++i) LPX_HIP_TRY(launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream));
+    r.enq += r.batch;
+    for (int k = 0; k < K; ++k)
+        LPX_HIP_TRY(hipMemcpyAsync(&g.hs[k], ts[r.idx[k]]->st, sizeof(DevState), hipMemcpyDeviceToHost, g.stream));
+    return 0;
+}
+
+int group_complete(GroupRun& r)
+{
+    GroupBuf& g = *r.g;
+    LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+    bool all = true;
+    for (size_t k = 0; k < r.idx.size(); ++k) if (g.hs[k].status == LPX_RUNNING) { all = false; break; }
+    r.done = all || r.enq >= r.budget;
+    return 0;
+}
+
+}  // namespace
+
+static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
+                             const lpx_run_opts* dopts, int* statuses, lpx_stats* stats)
+{
+    GroupRun runs[2];
+    for (int w = 0; w < 2; ++w) { runs[w].g = &g_groups[w]; runs[w].dual = w; }
+    for (int i = 0; i < count; ++i) runs[dual[i] ? 1 : 0].idx.push_back(i);
+    const double t0 = now_ms();
+    for (int w = 0; w < 2; ++w) if (!runs[w].idx.empty()) { int rc = group_begin(runs[w], ts, w ? dopts : popts); if (rc) return rc; }
+    for (;;) {
+        bool any = false;
+        for (int w = 0; w < 2; ++w) if (!runs[w].done) { int rc = group_submit(runs[w], ts, w ? dopts : popts); if (rc) return rc; any = true; }
+        if (!any) break;
+        for (int w = 0; w < 2; ++w) if (!runs[w].idx.empty() && runs[w].enq > 0 && !runs[w].done) { int rc = group_complete(runs[w]); if (rc) return rc; }
+    }
+    const double ms = now_ms() - t0;
+    for (int w = 0; w < 2; ++w) {
+        GroupRun& r = runs[w];
+        for (size_t k = 0; k < r.idx.size(); ++k) {
+            const DevState& s = r.g->hs[k];
+            const int i = r.idx[k];
+            *ts[i]->hst = s;
+            statuses[i] = s.status == LPX_RUNNING ? LPX_ITER_LIMIT : s.status;
+            if (stats) {
+                std::memset(&stats[i], 0, sizeof(lpx_stats));
+                stats[i].pivots = s.iter; stats[i].fdf_pivots = s.fdf_count;
+                stats[i].cleanup_pivots = w ? s.primal_count : 0;
+                stats[i].loop_ms = ms / (double)count;
+                stats[i].launches = 2 * r.enq / (long long)(r.idx.size() ? r.idx.size() : 1);
+            }
+        }
+    }
+    return 0;
+}
+
 extern "C" {
 
 int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)
@@ -473,6 +610,12 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
     lpx_run_opts pd, dd;
     if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
     if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
+    static const bool batched_env = [] { const char* e = std::getenv("LPX_BATCHED"); return !(e && e[0] == '0'); }();
+    if (batched_env && count >= 2 && !popts->profile && !dopts->profile) {
+        bool ok = true;
+        for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2 || (!dual[i] && !ts[i]->us)) ok = false;
+        if (ok) return multi_run_batched(ts, dual, count, popts, dopts, statuses, stats);
+    }
     std::vector<LoopRun> runs(count);
     std::vector<char> active(count, 0);
     for (int i = 0; i < count; ++i) {

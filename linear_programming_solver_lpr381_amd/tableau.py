@@ -145,3 +145,17 @@ def dual_tableau(T: np.ndarray, basis: np.ndarray, eps: float = 1e-9, ratio_tol:
                                       basis.ctypes.data_as(ip), eps, ratio_tol, fdf_guard, max_iter,
                                       cleanup, _wrap_cb(cb), None, C.byref(st)))
     return rc, st.as_dict()
+
+
+def multi_run(tableaux, dual, primal_opts: Optional[RunOpts] = None, dual_opts: Optional[RunOpts] = None):
+    """lpx_multi_run: runs several device tableaux to completion together (B&B node batches, K9).
+    Returns (statuses, [stats dict])."""
+    k = len(tableaux)
+    hs = (C.c_void_p * k)(*[t._h for t in tableaux])
+    dl = (C.c_int * k)(*[1 if d else 0 for d in dual])
+    st = (C.c_int * k)()
+    ss = (Stats * k)()
+    po = primal_opts if primal_opts is not None else default_opts(False)
+    do = dual_opts if dual_opts is not None else default_opts(True)
+    check(lib().lpx_multi_run(hs, dl, k, C.byref(po), C.byref(do), st, ss))
+    return list(st), [s.as_dict() for s in ss]

@@ -219,7 +219,7 @@ def primal_tableau(T, basis, eps=1e-9, max_iter=10000):
 
 def dual_tableau(T, basis, eps=1e-9, ratio_tol=1e-12, fdf_guard=100, max_iter=10000, cleanup=0):
     assert T.flags.c_contiguous and T.dtype == np.float64 and basis.dtype == np.int32
-    trace = np.zeros(2 * (3 * max(max_iter, 1) + 128), np.int32)
+    trace = np.zeros(2 * (max(fdf_guard, 0) + 2 * max(max_iter, 1) + 128), np.int32)   # FDF + dual loop + clean-up
     n = C.c_int(0)
     nf = C.c_int(0)
     st = lib().orc_dual_tableau(_d(T), T.shape[0], T.shape[1], _i(basis), eps, ratio_tol, fdf_guard,

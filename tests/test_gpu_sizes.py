@@ -181,3 +181,33 @@ def test_headline_shape_properties(gpu):
         last_r, last_q = int(rows[-1]), int(chosen2[-1])
         e2 = np.zeros(R); e2[last_r] = 1.0
         assert np.array_equal(T3[:, last_q], e2)
+
+
+def test_multi_run_batched_mixed_group(gpu, oracle):
+    """lpx_multi_run (K9): a mixed group of primal and dual tableaux of different shapes advances in
+    lockstep launches; every member must end bit-identical to its own sequential oracle run."""
+    specs = [(40, 60, 2, 0), (64, 100, 3, 0), (8, 12, 1, 0), (20, 30, 2, 5), (100, 160, 5, 30), (30, 45, 21, 0), (40, 64, 3, 10)]
+    tabs, refs, dual = [], [], []
+    for (m, n, seed, n_ge) in specs:
+        c, A, b = synth.dense_lp(m, n, seed=seed)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        if n_ge:
+            g = np.random.Generator(np.random.PCG64(seed + 99))
+            for i in g.choice(m, size=n_ge, replace=False):
+                T[i, :n] *= -1.0
+                T[i, -1] = -0.02 * T[i, -1]
+        Tr, br = T.copy(), basis.copy()
+        if n_ge:
+            st, tr, _ = oracle.dual_tableau(Tr, br, fdf_guard=10000, cleanup=1)
+        else:
+            st, tr = oracle.primal_tableau(Tr, br)
+        refs.append((st, tr, Tr, br))
+        tabs.append(gpu.DeviceTableau.from_host(T, basis))
+        dual.append(bool(n_ge))
+    statuses, stats = gpu.multi_run(tabs, dual, dual_opts=gpu.default_opts(True, fdf_guard=10000, cleanup=1))
+    for t, (st, tr, Tr, br), s, ss in zip(tabs, refs, statuses, stats):
+        Tg, bg = t.download()
+        assert s == st and ss["pivots"] == len(tr)
+        assert t.trace().tolist() == tr.tolist()
+        assert np.array_equal(_bits(Tg), _bits(Tr)) and bg.tolist() == br.tolist()
+        t.close()
