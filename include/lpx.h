@@ -170,6 +170,14 @@ int  lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, voi
 /* Bidx[m]; Nidx[n] in the reference's list order; xB[m]; *z = c_B . x_B of the minimised model. */
 int  lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB, double* z);
 int  lpx_revised_binv(lpx_revised* r, double* Binv /* [m*m] row-major */);
+/* K7': recompute [[B^-1, x_B], [c_B B^-1, z]] from the current basis with the device Gauss-Jordan below
+ * (what the reference does every iteration, :128-133).  lpx_revised_set_refactor(r, k) makes
+ * lpx_revised_run do it after every k iterations (0 = never, the default). */
+int  lpx_revised_refactor(lpx_revised* r);
+int  lpx_revised_set_refactor(lpx_revised* r, int every);
+/* Invert (Models/RevisedPrimalSimplex.cs:402-456), bit for bit: Gauss-Jordan with partial pivoting on
+ * [M | I]; M and inv are n x n row-major host buffers.  Returns 0 or LPX_E_SINGULAR (:426). */
+int  lpx_invert(const double* M, int n, double* inv);
 int  lpx_revised_trace(lpx_revised* r, int32_t* trace /* [2*cap]: (leaveRow, entering) */, int cap, int* n);
 /* one-shot on host buffers */
 int  lpx_revised_solve(const double* A, int m, int n, const double* c, const double* b,

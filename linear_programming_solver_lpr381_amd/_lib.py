@@ -128,6 +128,9 @@ def lib() -> C.CDLL:
     L.lpx_revised_run.argtypes = [vp, C.POINTER(RunOpts), PIVOT_CB, vp, C.POINTER(Stats)]
     L.lpx_revised_result.argtypes = [vp, ip, ip, dp, dp]
     L.lpx_revised_binv.argtypes = [vp, dp]
+    L.lpx_revised_refactor.argtypes = [vp]
+    L.lpx_revised_set_refactor.argtypes = [vp, C.c_int]
+    L.lpx_invert.argtypes = [dp, C.c_int, dp]
     L.lpx_revised_trace.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]
     L.lpx_revised_solve.argtypes = [dp, C.c_int, C.c_int, dp, dp, ip, ip, dp, dp, C.c_double, C.c_int,
                                     PIVOT_CB, vp, C.POINTER(Stats)]

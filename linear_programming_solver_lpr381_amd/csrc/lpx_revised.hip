@@ -198,6 +198,106 @@ __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K7': Invert (Models/RevisedPrimalSimplex.cs:402-456) on the device, bit for bit: Gauss-Jordan on the
+// augmented [M | I] (n x 2n) with partial pivoting -- first maximum of |a| on ties (:419-425), singular if
+// |pivot| < 1e-9 (:426), row swap (:428-434), scaling by true division (:437-438), elimination of every
+// other row over all 2n columns (:441-446).  One step = inv_select (one workgroup: pivot search, swap,
+// scale, column snapshot) + the tableau path's lpx_update on the n x 2n matrix (HBM-bound, 32 n^2 bytes).
+// Used for the periodic refactorisation of the revised path and exposed as lpx_invert.
+// ------------------------------------------------------------------------------------------------
+struct InvParams {
+    double* A; int ld; int n;          // augmented matrix, n rows, 2n columns
+    double* prow; double* pcol; DevState* st;
+};
+static constexpr int LPX_SINGULAR_STATUS = 5;
+
+__global__ __launch_bounds__(SEL_NT) void inv_select(InvParams P)
+{
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x;
+    const int n = P.n, w = 2 * n;
+    const size_t ld = (size_t)P.ld;
+    const int col = st->iter;
+    if (col >= n) { if (t == 0) { st->status = LPX_OPTIMAL; st->r = -1; } return; }
+    // pivotRow = first row >= col with the largest |A[r,col]|  -> lexicographic min of (-|a|, r)
+    MinIdx m; m.v = __builtin_inf(); m.i = INT_MAX;
+    for (int r = col + t; r < n; r += SEL_NT) {
+        const double v = -fabs(P.A[(size_t)r * ld + col]);
+        if (v < m.v) { m.v = v; m.i = r; }
+    }
+    m = block_min_idx(m, s_v, s_i);
+    const int prw = m.i;
+    if (prw == INT_MAX || !(-m.v >= 1e-9)) {                       // Math.Abs(...) < Eps -> singular (:426)
+        if (t == 0) { st->status = LPX_SINGULAR_STATUS; st->r = -1; }
+        return;
+    }
+    double* rc = P.A + (size_t)col * ld;
+    double* rp = P.A + (size_t)prw * ld;
+    const double piv = rp[col];                                    // value that lands in A[col,col] after the swap
+    __syncthreads();
+    for (int j = t; j < w; j += SEL_NT) {                          // swap (:428-434) fused with scaling (:437-438)
+        const double a = rc[j], b = rp[j];
+        const double p = b / piv;
+        rc[j] = p; P.prow[j] = p;
+        if (prw != col) rp[j] = a;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += SEL_NT) P.pcol[i] = (i == col) ? 0.0 : P.A[(size_t)i * ld + col];   // factors (:444)
+    if (t == 0) { st->iter = col + 1; st->r = col; st->qn = -1; }
+}
+
+// [M | I] from a packed n x n matrix already on the device
+__global__ __launch_bounds__(256) void inv_build(const double* __restrict__ M, int n, int ldm, double* __restrict__ A, int ld)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < n) v = M[(size_t)i * ldm + j];
+    else if (j == n + i) v = 1.0;
+    A[(size_t)i * ld + j] = v;
+}
+
+// basis matrix B = [A | I][:, Bidx] gathered from AT (GetSubmatrix, :58,:128)
+__global__ __launch_bounds__(256) void rv_gather_basis(RvParams P, double* __restrict__ M, int ldm)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, jb = blockIdx.y;     // M[i, jb] = column Bidx[jb], row i
+    if (i >= P.m) return;
+    const int col = P.Bidx[jb];
+    M[(size_t)i * ldm + jb] = (col < P.n) ? P.AT[(size_t)col * P.ldat + i] : ((i == col - P.n) ? 1.0 : 0.0);
+}
+
+// W <- [[inv, inv*b], [cB*inv, cB*xB]] after a refactorisation (Multiply :59/:132, MultiplyRow :71, Dot :61/:133)
+__global__ __launch_bounds__(256) void rv_refill_rows(RvParams P, const double* __restrict__ Ainv, int ldi, const double* __restrict__ b)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.m) return;
+    const double* src = Ainv + (size_t)i * ldi + P.m;                 // right half of the augmented matrix
+    double* dst = P.W + (size_t)i * P.ldw;
+    double s = 0.0;
+    for (int k = lane; k < P.m; k += 64) { const double v = src[k]; dst[k] = v; s += v * b[k]; }
+    s = wave_sum(s);
+    if (lane == 0) { dst[P.m] = s; P.rhsbuf[i] = s; }
+}
+__global__ __launch_bounds__(256) void rv_refill_pi(RvParams P, const double* __restrict__ call)
+{
+    // pi_j = sum_i cB_i * W[i,j]  (one lane per column, rows ascending as MultiplyRow does), z = cB . xB
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > P.m) return;
+    double s = 0.0;
+    for (int i = 0; i < P.m; ++i) {
+        const int col = P.Bidx[i];
+        const double cb = col < P.n ? call[col] : 0.0;
+        s += cb * P.W[(size_t)i * P.ldw + j];
+    }
+    P.W[(size_t)P.m * P.ldw + j] = s;
+    if (j == P.m) P.rhsbuf[P.m] = s;
+}
+
 }  // namespace lpx
 
 // ---------------------------------------------------------------------------------------------------
@@ -205,17 +305,77 @@ __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
 // ---------------------------------------------------------------------------------------------------
 using namespace lpx;
 
+namespace {
+
+struct InvWork {
+    int n = 0, ld = 0; double* A = nullptr; double* prow = nullptr; double* pcol = nullptr;
+    DevState* st = nullptr; DevState* hst = nullptr; hipStream_t stream = nullptr;
+    hipGraphExec_t gexec = nullptr; int g_batch = 0; std::string g_key; std::vector<hipEvent_t> events;
+    ~InvWork() {
+        if (stream) hipStreamSynchronize(stream);
+        if (gexec) hipGraphExecDestroy(gexec);
+        hipFree(A); hipFree(prow); hipFree(pcol); hipFree(st);
+        if (hst) hipHostFree(hst);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+int inv_alloc(InvWork& w, int n)
+{
+    w.n = n; w.ld = (2 * n + 15) / 16 * 16;
+    LPX_HIP_TRY(hipMalloc((void**)&w.A, sizeof(double) * (size_t)n * w.ld));
+    LPX_HIP_TRY(hipMalloc((void**)&w.prow, sizeof(double) * w.ld));
+    LPX_HIP_TRY(hipMalloc((void**)&w.pcol, sizeof(double) * n));
+    LPX_HIP_TRY(hipMalloc((void**)&w.st, sizeof(DevState)));
+    LPX_HIP_TRY(hipHostMalloc((void**)&w.hst, sizeof(DevState)));
+    LPX_HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    LPX_HIP_TRY(hipMemsetAsync(w.prow, 0, sizeof(double) * w.ld, w.stream));
+    return 0;
+}
+
+// runs the n Gauss-Jordan steps on w.A (already holding [M | I]); returns 0 or LPX_E_SINGULAR
+int inv_run(InvWork& w)
+{
+    InvParams ip; ip.A = w.A; ip.ld = w.ld; ip.n = w.n; ip.prow = w.prow; ip.pcol = w.pcol; ip.st = w.st;
+    LoopCtx c;
+    c.stream = w.stream; c.st = w.st; c.hst = w.hst; c.trace = nullptr; c.trace_cap = 0;
+    c.events = &w.events; c.gexec = &w.gexec; c.g_batch = &w.g_batch; c.g_key = &w.g_key;
+    c.key.assign(reinterpret_cast<const char*>(&ip), sizeof(ip));
+    InvWork* pw = &w;
+    c.enqueue_iter = [pw, ip](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int {
+        hipLaunchKernelGGL(inv_select, dim3(1), dim3(SEL_NT), 0, s, ip);
+        LPX_HIP_TRY(hipGetLastError());
+        LPX_HIP_TRY(launch_update(pw->A, pw->ld, pw->n, 2 * pw->n, nullptr, pw->prow, pw->pcol, pw->pcol, nullptr, pw->st, s, e0, e1));
+        return 0;
+    };
+    c.launches_per_iter = 2; c.profile_maps = true;
+    DevState init; std::memset(&init, 0, sizeof(init));
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
+    lpx_run_opts o; lpx_default_opts(&o, 0); o.batch = 64;
+    int st = run_device_loop(c, init, &o, (long long)w.n + 2, nullptr, nullptr, nullptr);
+    if (st < 0) return st;
+    if (st == LPX_SINGULAR_STATUS) { set_error("Singular basis encountered."); return LPX_E_SINGULAR; }
+    if (st != LPX_OPTIMAL) { set_error("inversion did not finish"); return LPX_EDEVICE; }
+    return 0;
+}
+
+}  // namespace
+
 struct lpx_revised {
     int m = 0, n = 0, ldat = 0, ldw = 0;
     double *AT = nullptr, *c = nullptr, *W = nullptr, *prow = nullptr, *fac = nullptr, *rhsbuf = nullptr,
            *rc = nullptr, *aq = nullptr, *ws = nullptr;
     int32_t *Bidx = nullptr, *key = nullptr, *trace = nullptr;
     int trace_cap = 1 << 16;
+    double* b = nullptr;            // right-hand sides (refactorisation)
+    double* Mb = nullptr;           // m x m basis matrix scratch
+    InvWork* inv = nullptr; int refactor_every = 0;
     DevState* st = nullptr; DevState* hst = nullptr;
     hipStream_t stream = nullptr;
     hipGraphExec_t gexec = nullptr; int g_batch = 0; std::string g_key;
     std::vector<hipEvent_t> events;
 };
+
 
 static RvParams rv_params(lpx_revised* r, const lpx_run_opts* o)
 {
@@ -249,7 +409,8 @@ void lpx_revised_destroy(lpx_revised* r)
     for (hipEvent_t e : r->events) hipEventDestroy(e);
     hipFree(r->AT); hipFree(r->c); hipFree(r->W); hipFree(r->prow); hipFree(r->fac); hipFree(r->rhsbuf);
     hipFree(r->rc); hipFree(r->aq); hipFree(r->ws); hipFree(r->Bidx); hipFree(r->key); hipFree(r->trace);
-    hipFree(r->st);
+    hipFree(r->st); hipFree(r->b); hipFree(r->Mb);
+    delete r->inv;
     if (r->hst) hipHostFree(r->hst);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
@@ -278,6 +439,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     RALLOC(r->Bidx, sizeof(int32_t) * m); RALLOC(r->key, sizeof(int32_t) * (n + m));
     RALLOC(r->trace, sizeof(int32_t) * 2 * r->trace_cap); RALLOC(r->st, sizeof(DevState));
     RALLOC(Atmp, sizeof(double) * (size_t)m * n);
+    RALLOC(r->b, sizeof(double) * m);
 #undef RALLOC
     if (hipHostMalloc((void**)&r->hst, sizeof(DevState)) != hipSuccess ||
         hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -299,6 +461,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     hipMemcpy2DAsync(r->W, sizeof(double) * (r->ldw + 1), one.data(), sizeof(double), sizeof(double), m, hipMemcpyHostToDevice, s);
     hipMemcpy2DAsync(r->W + m, sizeof(double) * r->ldw, b, sizeof(double), sizeof(double), m, hipMemcpyHostToDevice, s);
     hipMemcpyAsync(r->rhsbuf, b, sizeof(double) * m, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(r->b, b, sizeof(double) * m, hipMemcpyHostToDevice, s);
     std::vector<int32_t> bidx(m), key(n + m);
     for (int i = 0; i < m; ++i) bidx[i] = n + i;                 // :47
     for (int j = 0; j < n; ++j) key[j] = j;                       // :48
@@ -315,10 +478,68 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     return 0;
 }
 
+int lpx_revised_refactor(lpx_revised* r)
+{
+    if (!r) { set_error("lpx_revised_refactor: null handle"); return LPX_EINVAL; }
+    const int m = r->m;
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    if (!r->inv) {
+        r->inv = new InvWork();
+        int rc = inv_alloc(*r->inv, m);
+        if (rc) { delete r->inv; r->inv = nullptr; return rc; }
+        LPX_HIP_TRY(hipMalloc((void**)&r->Mb, sizeof(double) * (size_t)m * m));
+    }
+    lpx_run_opts od; lpx_default_opts(&od, 1);
+    RvParams p = rv_params(r, &od);
+    InvWork& w = *r->inv;
+    hipLaunchKernelGGL(rv_gather_basis, dim3((m + 255) / 256, m), dim3(256), 0, w.stream, p, r->Mb, m);
+    hipLaunchKernelGGL(inv_build, dim3((w.ld + 255) / 256, m), dim3(256), 0, w.stream, (const double*)r->Mb, m, m, w.A, w.ld);
+    LPX_HIP_TRY(hipGetLastError());
+    int rc = inv_run(w);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rv_refill_rows, dim3((m + 3) / 4), dim3(256), 0, w.stream, p, (const double*)w.A, w.ld, (const double*)r->b);
+    hipLaunchKernelGGL(rv_refill_pi, dim3((m + 1 + 255) / 256), dim3(256), 0, w.stream, p, (const double*)r->c);
+    LPX_HIP_TRY(hipGetLastError());
+    LPX_HIP_TRY(hipStreamSynchronize(w.stream));
+    return 0;
+}
+
+int lpx_revised_set_refactor(lpx_revised* r, int every)
+{
+    if (!r || every < 0) return LPX_EINVAL;
+    r->refactor_every = every;
+    return 0;
+}
+
+static int revised_run_segment(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st, int iter0);
+
 int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)
 {
     if (!r) { set_error("lpx_revised_run: null handle"); return LPX_EINVAL; }
     lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
+    if (r->refactor_every <= 0) return revised_run_segment(r, o, cb, user, st, 0);
+    // segments of `refactor_every` iterations, B^-1 recomputed from the basis in between (K7')
+    lpx_stats total; std::memset(&total, 0, sizeof(total));
+    int done = 0, status = LPX_ITER_LIMIT;
+    while (done < o->max_iter) {
+        lpx_run_opts seg = *o;
+        seg.max_iter = std::min(o->max_iter, done + r->refactor_every);
+        lpx_stats s1; std::memset(&s1, 0, sizeof(s1));
+        status = revised_run_segment(r, &seg, cb, user, &s1, done);
+        total.launches += s1.launches; total.loop_ms += s1.loop_ms; total.update_ms_sum += s1.update_ms_sum;
+        total.update_launches += s1.update_launches; total.pivots = s1.pivots;
+        if (status != LPX_ITER_LIMIT) break;
+        done = (int)s1.pivots;
+        if (done >= o->max_iter) break;
+        int rc = lpx_revised_refactor(r);
+        if (rc) return rc;
+    }
+    if (st) { double h = st->h2d_ms, dd = st->d2h_ms; *st = total; st->h2d_ms = h; st->d2h_ms = dd; }
+    return status;
+}
+
+static int revised_run_segment(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st, int iter0)
+{
     RvParams p = rv_params(r, o);
     LoopCtx c;
     c.stream = r->stream; c.st = r->st; c.hst = r->hst; c.trace = r->trace; c.trace_cap = r->trace_cap;
@@ -329,10 +550,31 @@ int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void
     c.profile_maps = true;
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
+    init.iter = iter0;             // continuing after a refactorisation keeps the iteration count and the trace
     // continue from the handle's current basis: the order-key counter lives in pad[0]
     LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
     init.pad[0] = r->hst->pad[0] > 0 ? r->hst->pad[0] : r->n;
     return run_device_loop(c, init, o, (long long)o->max_iter + 2, cb, user, st);
+}
+
+int lpx_invert(const double* M, int n, double* inv)
+{
+    if (!M || !inv || n < 1) { set_error("lpx_invert: bad argument"); return LPX_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    InvWork w;
+    rc = inv_alloc(w, n);
+    if (rc) return rc;
+    double* Md = nullptr;
+    LPX_HIP_TRY(hipMalloc((void**)&Md, sizeof(double) * (size_t)n * n));
+    hipError_t e = hipMemcpyAsync(Md, M, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, w.stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(inv_build, dim3((w.ld + 255) / 256, n), dim3(256), 0, w.stream, (const double*)Md, n, n, w.A, w.ld); e = hipGetLastError(); }
+    if (e != hipSuccess) { hipFree(Md); set_error(std::string("lpx_invert: ") + hipGetErrorString(e)); return LPX_EDEVICE; }
+    rc = inv_run(w);
+    hipFree(Md);
+    if (rc) return rc;
+    LPX_HIP_TRY(hipMemcpy2D(inv, sizeof(double) * n, w.A + n, sizeof(double) * w.ld, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB, double* z)

@@ -70,3 +70,19 @@ class DeviceRevised:
         tr = np.zeros((max(n.value, 1), 2), np.int32)
         check(lib().lpx_revised_trace(self._h, tr.ctypes.data_as(ip), n.value, C.byref(n)))
         return tr[: n.value].copy()
+
+    def refactor(self):
+        """K7': recompute B^-1, x_B, pi, z from the current basis (device Gauss-Jordan, Invert :402-456)."""
+        check(lib().lpx_revised_refactor(self._h))
+
+    def set_refactor(self, every: int):
+        check(lib().lpx_revised_set_refactor(self._h, int(every)))
+
+
+def invert(M: np.ndarray) -> np.ndarray:
+    """lpx_invert: the reference's Invert (Models/RevisedPrimalSimplex.cs:402-456) on the GPU, bit for bit."""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    assert M.ndim == 2 and M.shape[0] == M.shape[1]
+    inv = np.zeros_like(M)
+    check(lib().lpx_invert(M.ctypes.data_as(dp), M.shape[0], inv.ctypes.data_as(dp)))
+    return inv

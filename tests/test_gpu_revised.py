@@ -73,3 +73,61 @@ def test_revised_one_shot(gpu, oracle):
                                        xB.ctypes.data_as(dp), C.byref(z), 1e-9, 10000, NULL_CB, None, C.byref(st)))
     assert rc == 0 and Bidx.tolist() == ref.Bidx.tolist() and st.pivots == len(ref.trace)
     assert abs(z.value - ref.z_internal) <= REL * abs(ref.z_internal)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (12, 3), (100, 4), (257, 5), (600, 6)])
+def test_invert_bitwise_vs_oracle(gpu, oracle, n, seed):
+    """K7' / SURVEY a19: Invert (Gauss-Jordan, partial pivoting, first max on ties) bit for bit."""
+    g = np.random.default_rng(seed)
+    M = g.uniform(-1, 1, size=(n, n))
+    if n > 2:
+        M[0, :] = M[1, :] * 0 + M[0, :]          # keep generic
+        M[2, 0] = -M[1, 0]                       # a tie in |a| on the first column: the first row must win
+    rc, ref = oracle.invert(M)
+    assert rc == 0
+    inv = gpu.invert(M)
+    assert np.array_equal(inv.view(np.uint64), ref.view(np.uint64))
+    assert np.allclose(inv @ M, np.eye(n), atol=1e-8)
+
+
+def test_invert_singular(gpu, oracle):
+    M = np.ones((5, 5))
+    assert oracle.invert(M)[0] == oracle.E_SINGULAR
+    with pytest.raises(gpu.LpxError) as e:
+        gpu.invert(M)
+    assert e.value.code == gpu._lib.E_SINGULAR and "Singular basis encountered." in str(e.value)
+
+
+@pytest.mark.parametrize("every", [1, 3, 7])
+def test_revised_with_periodic_refactorisation(gpu, oracle, every):
+    """With refactor_every = 1 the engine recomputes B^-1 from the basis after every iteration, as the
+    reference does (RevisedPrimalSimplex.cs:128); any interval must give the oracle's pivots."""
+    m, n, seed = 40, 64, 3
+    c, A, b = synth.dense_lp(m, n, seed=seed)
+    ref = oracle.revised_solve(oracle.Problem(oracle.MAX, c, A, np.zeros(m, np.int32), b))
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.set_refactor(every)
+        status, st = rv.run()
+        Bidx, Nidx, xB, z = rv.result()
+        tr = rv.trace()
+        Binv = rv.binv()
+    assert status == 0 and tr.tolist() == ref.trace.tolist() and st["pivots"] == len(ref.trace)
+    assert Bidx.tolist() == ref.Bidx.tolist() and Nidx.tolist() == ref.Nidx.tolist()
+    assert abs(z - ref.z_internal) <= REL * abs(ref.z_internal)
+    full = np.hstack([A, np.eye(m)])
+    assert np.allclose(Binv @ full[:, Bidx], np.eye(m), atol=1e-9)
+
+
+def test_refactor_restores_exact_inverse(gpu, oracle):
+    m, n = 30, 45
+    c, A, b = synth.dense_lp(m, n, seed=21)
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.run()
+        Bidx, _, xB0, z0 = rv.result()
+        rv.refactor()
+        _, _, xB1, z1 = rv.result()
+        Binv = rv.binv()
+    full = np.hstack([A, np.eye(m)])
+    rc, ref = oracle.invert(np.ascontiguousarray(full[:, Bidx]))
+    assert rc == 0 and np.array_equal(Binv.view(np.uint64), ref.view(np.uint64))     # same Invert, same bits
+    assert np.allclose(xB1, xB0, rtol=1e-10, atol=1e-10) and abs(z1 - z0) <= 1e-10 * abs(z0)
