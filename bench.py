@@ -240,12 +240,19 @@ def main():
         rv.close()
         rv = L.DeviceRevised(A3, -c3, b3)
         st3, s3 = rv.run(max_iter=args.revised_iters, batch=50)
+        t3 = time.perf_counter()
+        rv.refactor()                                   # K7': device Gauss-Jordan of the 4096x4096 basis
+        refac_s = time.perf_counter() - t3
         out["revised"] = {"workload": "dense random LP m=4096 n=8192, revised simplex (config 3), "
                                       f"first {s3['pivots']} iterations from the slack basis",
                           "iterations_per_s": s3["pivots"] / (s3["loop_ms"] * 1e-3),
                           "us_per_iteration": 1e3 * s3["loop_ms"] / max(s3["pivots"], 1),
                           "unfused_reference_bytes_per_iteration": 8.0 * (5 * 4096 ** 2 + 4096 * 8192),
-                          "engine_bytes_per_iteration": 8.0 * (4096 * 8192 + 4096 ** 2) + 16.0 * 4097 * 4097}
+                          "engine_bytes_per_iteration": 8.0 * (4096 * 8192 + 4096 ** 2) + 16.0 * 4097 * 4097,
+                          "refactor_s": refac_s,
+                          "refactor_algorithmic_gbs": 32.0 * 4096 ** 3 / refac_s / 1e9,
+                          "refactor_note": "K7' = the reference's Invert (4096 Gauss-Jordan steps x 16*m*2m bytes), "
+                                           "which the reference runs EVERY iteration; the engine runs it on demand"}
         rv.close()
         # ---- CPU baseline: oracle (C port of the reference loops), 1 core -------------------------------
         if world == 1:
