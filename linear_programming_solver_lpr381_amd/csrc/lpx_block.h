@@ -150,6 +150,14 @@ __device__ inline int block_excl_scan_sum(int x, int* s_i, int* total)
 // test of another -- and value(den, num), which returns +inf for ineligible entries.
 // ------------------------------------------------------------------------------------------------
 static constexpr int WH_PER = 16;
+#ifdef LPX_STAMPS
+__device__ unsigned long long lpx_g_stamps[32];
+#define LPX_HS(slot) do { if (threadIdx.x == 0 && blockIdx.x == 1) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); lpx_g_stamps[(slot)] += n_ - hs_prev_; hs_prev_ = n_; } } while (0)
+#define LPX_HS_BEGIN unsigned long long hs_prev_ = __builtin_amdgcn_s_memtime();
+#else
+#define LPX_HS(slot) do {} while (0)
+#define LPX_HS_BEGIN
+#endif
 
 template <class Src>
 __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src)
@@ -157,8 +165,9 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
     const int lane = threadIdx.x & 63;
     double best = __builtin_inf();
     int win = -1;
+    LPX_HS_BEGIN
     for (int seg = 0; seg < L; seg += 64 * WH_PER) {
-        double den[WH_PER], num[WH_PER], rt[WH_PER];
+        decltype(src.den(0)) den[WH_PER]; double num[WH_PER], rt[WH_PER];
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) {
             // clamped index instead of a guard: a guarded load becomes its own exec-masked branch with
@@ -166,11 +175,14 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
             const int k = min(seg + u * 64 + lane, L - 1);
             den[u] = src.den(k); num[u] = src.num(k);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LPX_HS(0);
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) {
             const int k = seg + u * 64 + lane;
             rt[u] = (k < L) ? src.value(den[u], num[u]) : __builtin_inf();
         }
+        LPX_HS(1);
         // Fast path.  Let rmin be the segment minimum and i* its first position.  No row of the segment
         // can be accepted unless rmin < fl(best - tol) (every ratio is >= rmin).  If that holds and every
         // OTHER row j has fl(r_j - tol) > rmin, then i* is accepted when the scan reaches it (whatever
@@ -181,14 +193,17 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) if (rt[u] < lm.v) { lm.v = rt[u]; lm.i = u * 64 + lane; }
         lm = wave_min_idx(lm);
+        LPX_HS(2);
         if (!(lm.v < best - tol)) continue;              // nothing in this segment beats the carried best
         int inband = 0;
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) inband += ((rt[u] - tol) <= lm.v) ? 1 : 0;
         if (__ballot(inband >= 2) == 0ull && __popcll(__ballot(inband == 1)) == 1) {
             best = lm.v; win = seg + lm.i;
+            LPX_HS(3);
             continue;
         }
+        LPX_HS(4);
         int pos = -1;                                   // last accepted position inside this segment
         for (;;) {
             const double thr = best - tol;
@@ -211,6 +226,7 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
             win = seg + found;
             pos = found;
         }
+        LPX_HS(5);
     }
     return win;
 }
@@ -237,6 +253,15 @@ struct RowRatio {
     __device__ __forceinline__ double den(int i) const { return col[(size_t)i * cs]; }
     __device__ __forceinline__ double num(int i) const { return rhs[(size_t)i * rs]; }
     __device__ __forceinline__ double value(double a, double b) const { return a > eps ? b / a : __builtin_inf(); }
+};
+// rows, with the factor column living in one of two ping-pong buffers chosen by a parity that is itself
+// still in flight: both candidates are loaded (den is a pair) so the loads do not wait for the state record
+struct RowRatioPP {
+    const double* c0; const double* c1; const double* rhs; double eps; int par;
+    struct Den { double a0, a1; };
+    __device__ __forceinline__ Den den(int i) const { Den d; d.a0 = c0[i]; d.a1 = c1[i]; return d; }
+    __device__ __forceinline__ double num(int i) const { return rhs[i]; }
+    __device__ __forceinline__ double value(Den d, double b) const { const double a = par ? d.a1 : d.a0; return a > eps ? b / a : __builtin_inf(); }
 };
 // columns of the dual loop: den = T[r,j], num = T[m,j], eligible den < -eps, ratio = num/(-den)
 //       (Models/DualSimplex.cs:79-91)

@@ -437,7 +437,7 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
         if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
         else if (q < 0) final_status = LPX_OPTIMAL;
         else {
-            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps});   // every wave, no barrier
+            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatioPP{P.col0, P.col1, P.rhsbuf, P.eps, iter & 1});   // every wave, no barrier
             if (r < 0) final_status = LPX_UNBOUNDED;
             scanrow = m;
         }
@@ -498,9 +498,34 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
                                                    const int32_t* __restrict__ part_i, int nblk,
                                                    int forced, int ncw, int nunits)
 {
+    // Everything that does not depend on the state record is issued first: the tableau tile, the pivot-row
+    // slice and BOTH candidate factor columns (the parity that picks one is part of the state).  The state
+    // record is only needed to decide what to store.
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    const int cw = unit % ncw;
+    const int rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    const int row0 = rb * UPD_ROWS;
+    const bool live = (unit < nunits) && (col < ld) && (row0 < Rcap);
+    double* base = T + (size_t)row0 * ld + col;
+    double2 p = make_double2(0.0, 0.0);
+    double2 v[UPD_ROWS];
+    double f0[UPD_ROWS], f1[UPD_ROWS];
+    if (live) {
+        p = *reinterpret_cast<const double2*>(prow + col);
+#pragma unroll
+        for (int k = 0; k < UPD_ROWS; ++k) {
+            const int i = row0 + k;
+            if (i < Rcap) {
+                v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+                f0[k] = fac0[i]; f1[k] = fac1[i];
+            }
+        }
+    }
     const int status = st->status;
     const int r = st->r;
-    const int lane = threadIdx.x & 63;
     const int R = shape ? shape[0] : Rcap, C = shape ? shape[1] : Ccap;
     if (status != LPX_RUNNING) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { us->status = status; us->iter = st->iter; }
@@ -524,42 +549,20 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
         us->status = LPX_RUNNING; us->iter = st->iter; us->qn = qn;
         us->primal_count = st->primal_count; us->forced_k = st->forced_k;
     }
-    if (r < 0) return;                                   // skipped pivot: nothing to update
+    if (r < 0 || !live || row0 >= R) return;             // skipped pivot / outside the live shape
     const int par = (st->iter - 1) & 1;
-    const double* __restrict__ fac = par ? fac1 : fac0;
     double* __restrict__ nxt = par ? fac0 : fac1;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
-    if (unit >= nunits) return;
-    const int cw = unit % ncw;
-    const int rb = unit / ncw;
-    const int col = cw * 128 + lane * 2;
-    if (col >= ld) return;
-    const double2 p = *reinterpret_cast<const double2*>(prow + col);
-    const int row0 = rb * UPD_ROWS;
-    if (row0 >= R) return;                                // capacity-sized grid: rows beyond the live shape
-    double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);
     const bool wr = (((C - 1) & ~1) == col);
-
-    double2 v[UPD_ROWS];
-    double f[UPD_ROWS];
-#pragma unroll
-    for (int k = 0; k < UPD_ROWS; ++k) {
-        const int i = row0 + k;
-        if (i < R) {
-            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
-            f[k] = fac[i];
-        }
-    }
 #pragma unroll
     for (int k = 0; k < UPD_ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
             double2 o;
             if (i != r) {
-                o.x = v[k].x - f[k] * p.x;      // mul, then sub: contraction is off
-                o.y = v[k].y - f[k] * p.y;
+                const double f = par ? f1[k] : f0[k];
+                o.x = v[k].x - f * p.x;         // mul, then sub: contraction is off
+                o.y = v[k].y - f * p.y;
                 *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
             } else {
                 o = p;                          // row r already holds the normalised pivot row
@@ -657,6 +660,15 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+#ifdef LPX_STAMPS
+hipError_t debug_copy_stamps(unsigned long long* out, int clear)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(lpx_g_stamps), sizeof(unsigned long long) * 32);
+    if (e == hipSuccess && clear) { unsigned long long z[32] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(lpx_g_stamps), z, sizeof(z)); }
+    return e;
+}
+#endif
+
 hipError_t kernels_init() { return hipSuccess; }
 
 hipError_t launch_select(const SelParams& p, hipStream_t s)

@@ -241,6 +241,8 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
 }
 
 #ifdef LPX_STAMPS
+extern "C++" { namespace lpx { hipError_t debug_copy_stamps(unsigned long long* out, int clear); } }
+int lpx_debug_hs(unsigned long long* out, int clear) { LPX_HIP_TRY(lpx::debug_copy_stamps(out, clear)); return 0; }
 int lpx_debug_ws(lpx_tableau* t, unsigned long long* out, int n, int clear)
 {
     double* src = t->us ? t->part_v + 128 : t->ws;

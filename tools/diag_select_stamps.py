@@ -21,9 +21,12 @@ dt.primal_run()
 dt.restore()
 out = (C.c_ulonglong * 16)()
 lib.lpx_debug_ws(dt._h, out, 16, 1)
+hs = (C.c_ulonglong * 32)()
+lib.lpx_debug_hs(hs, 1)
 
 status, st = dt.primal_run(use_graph=1, batch=64)
 lib.lpx_debug_ws(dt._h, out, 16, 0)
+lib.lpx_debug_hs(hs, 0)
 v = list(out)
 calls = v[15]
 names = ["state load+branch", "ratio test (hysteresis)", "row normalise + lookahead loop", "block argmin", "tail stores"]
@@ -34,3 +37,7 @@ print(f"in-kernel clock ~{clk:.2f} GHz; total stamped {tot/calls:.0f} cycles/cal
 for nm, x in zip(names, v[:5]):
     print(f"  {nm:34s} {x/calls:9.0f} cycles  {100*x/tot:5.1f}%")
 
+hn = ["operand loads (32/lane)", "16 divisions", "local min + DPP reduce", "band check (fast path taken)", "band check (slow path)", "ballot chain"]
+print("ratio scan breakdown (workgroup 1, wave 0; the lpx_g_stamps symbol is per code object):")
+for nm, x in zip(hn, list(hs)[:6]):
+    print(f"  {nm:34s} {x/calls:9.0f} cycles")
