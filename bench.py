@@ -85,10 +85,19 @@ def main():
     import linear_programming_solver_lpr381_amd as L
     from linear_programming_solver_lpr381_amd import synth
 
-    torch.cuda.set_device(local_rank)
-    L._lib.check(L._lib.lib().lpx_init(local_rank))
+    # LPX_BENCH_BACKEND=gloo is a REHEARSAL switch: several ranks share the GPUs that are visible (rank r
+    # uses device r % device_count) and the collectives run over gloo on CPU tensors.  The driver's runs
+    # use the default: one rank per GPU, RCCL ("nccl").
+    backend = os.environ.get("LPX_BENCH_BACKEND", "nccl")
+    dev = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev)
+    L._lib.check(L._lib.lib().lpx_init(dev))
+    coll_dev = "cpu" if backend == "gloo" else "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     def barrier():
         if world > 1:
@@ -99,15 +108,15 @@ def main():
         """X1: the incumbent exchange -- one RCCL all-reduce(max) over xGMI per level / round."""
         if world == 1:
             return vals
-        t = torch.from_numpy(np.ascontiguousarray(vals)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(vals)).to(coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
     def reduce_sum_max(count, seconds):
         if world == 1:
             return float(count), float(seconds)
-        a = torch.tensor([float(count)], dtype=torch.float64, device="cuda")
-        b = torch.tensor([float(seconds)], dtype=torch.float64, device="cuda")
+        a = torch.tensor([float(count)], dtype=torch.float64, device=coll_dev)
+        b = torch.tensor([float(seconds)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         dist.all_reduce(b, op=dist.ReduceOp.MAX)
         return float(a.item()), float(b.item())

@@ -69,6 +69,7 @@ struct Ctx {
     const LPProblem* root; EngineOptions opt; UpdatePivot cb;
     double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
     SimplexResult* out; HandlePool pool; bool stop = false;
+    bool count_work = true;      // false while this rank only mirrors the replicated warm-up of rank 0
     // resident root templates: the prepared root tableau as the primal / dual path builds it
     lpx_tableau* root_tpl[2] = {nullptr, nullptr}; int tplR[2] = {0, 0}, tplC[2] = {0, 0}; bool tpl_bad[2] = {false, false};
     ~Ctx() { lpx_tableau_destroy(root_tpl[0]); lpx_tableau_destroy(root_tpl[1]); }
@@ -211,7 +212,7 @@ void upload(Ctx& c, NodeLP& lp)
 void collect(Ctx& c, NodeLP& lp, int status, const lpx_stats& st, int nvars)
 {
     lp.pivots = st.pivots;
-    c.out->Stats.pivots += st.pivots; c.out->Stats.launches += st.launches; c.out->Stats.loop_ms += st.loop_ms;
+    if (c.count_work) { c.out->Stats.pivots += st.pivots; c.out->Stats.launches += st.launches; c.out->Stats.loop_ms += st.loop_ms; }
     if (status < 0) throw LpxException(status, "liblpx: " + last_error());
     lp.status = status;
     if (status == LPX_ITER_LIMIT) { lp.error = true; }              // exception in the reference
@@ -233,7 +234,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
     if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
         for (NodeLP* lp : group) {
-            c.out->LpSolves++;
+            if (c.count_work) c.out->LpSolves++;
             if (lp->error || lp->R < 2) { lp->error = true; continue; }
             lp->x.assign(nvars, 0.0);
             int64_t piv = 0;
@@ -255,7 +256,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             upload(c, *lp);
             hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
         }
-        c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
+        if (c.count_work) c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
         if (hs.empty()) continue;
         std::vector<int> st(hs.size()); std::vector<lpx_stats> ss(hs.size());
         int rc = lpx_multi_run(hs.data(), dual.data(), (int)hs.size(), &po, &dopt, st.data(), ss.data());
@@ -341,9 +342,12 @@ struct FNode { std::vector<Cut> cuts; int depth; };
 void LevelSearch(Ctx& c)
 {
     const int world = std::max(1, c.opt.world), rank = c.opt.rank;
-    const size_t want = (size_t)world * (size_t)std::max(1, c.opt.concurrent_nodes);
+    // The replicated warm-up only has to seed every rank with a subtree: 2 nodes per rank.  Its solves are
+    // redundant across ranks, so only rank 0 counts them (LpSolves / Nodes stay whole-job totals when summed).
+    const size_t want = (size_t)world * 2;
     std::vector<FNode> frontier{FNode{{}, 0}};
     bool replicated = world > 1;
+    c.count_work = !(replicated && rank != 0);
     for (;;) {
         if (replicated && frontier.size() >= want) {
             // hand the replicated frontier out: node i -> rank i % world, subtrees stay local from here on
@@ -351,6 +355,7 @@ void LevelSearch(Ctx& c)
             for (size_t i = 0; i < frontier.size(); ++i) if ((int)(i % world) == rank) mine.push_back(std::move(frontier[i]));
             frontier.swap(mine);
             replicated = false;
+            c.count_work = true;
         }
         // solve this level
         std::vector<NodeLP> lps(frontier.size());
@@ -358,7 +363,7 @@ void LevelSearch(Ctx& c)
         std::vector<char> skip(frontier.size(), 0);
         for (size_t i = 0; i < frontier.size(); ++i) {
             if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
-            c.out->Nodes++;
+            if (c.count_work) c.out->Nodes++;
             if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
             if (c.opt.test_node_lp) prepare(c, make_node(*c.root, frontier[i].cuts), lps[i]); else prepare_device(c, frontier[i].cuts, lps[i]);
             group.push_back(&lps[i]);

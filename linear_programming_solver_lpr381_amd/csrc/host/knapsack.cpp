@@ -68,6 +68,7 @@ struct Search {
     std::vector<double> profit, weight; std::vector<int32_t> order;
     double best = -INFINITY; std::vector<int32_t> bestX; bool has_best = false;
     int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0;
+    int64_t redundant_popped = 0, redundant_relax = 0;   // replicated warm-up on ranks != 0
     int spec = 64;
     std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
 
@@ -251,6 +252,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
             for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i]);
             pq.d.swap(mine.d);
             replicated = false;
+            if (rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }   // rank 0 accounts for the warm-up
         }
         bool more = true;
         for (int it = 0; it < round && more; ++it) {
@@ -299,8 +301,10 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     res.OptimalValue = S.has_best ? S.best : -INFINITY;
     res.Solution.assign(S.bestX.begin(), S.bestX.end());
     res.HasSolution = false;
-    res.Nodes = S.popped; res.LpSolves = S.relaxations;
-    res.NodeZ = {(double)S.relaxations, (double)S.popped, (double)S.expanded, (double)S.max_heap};
+    // whole-job totals when summed over ranks: the replicated warm-up is counted by rank 0 only
+    if (world > 1 && replicated && rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }
+    res.Nodes = S.popped - S.redundant_popped; res.LpSolves = S.relaxations - S.redundant_relax;
+    res.NodeZ = {(double)(S.relaxations - S.redundant_relax), (double)(S.popped - S.redundant_popped), (double)S.expanded, (double)S.max_heap};
     res.Stats.launches = S.launches;
     return res;
 }

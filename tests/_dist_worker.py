@@ -78,6 +78,9 @@ def main():
                          allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p)
     res["bnb"] = {"z": r.OptimalValue, "x": r.Solution.tolist(), "lp_solves": r.LpSolves, "nodes": r.Nodes,
                   "allreduces": calls["n"]}
+    if rank == 0:
+        one = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, test_node_lp=node_lp).Solve(p)
+        res["bnb_single"] = {"z": one.OptimalValue, "lp_solves": one.LpSolves}
     ref = O.bnb_solve(O.Problem(O.MAX, c, Af, np.zeros(m + n, np.int32), bf), 1)
     res["bnb_ref"] = {"z": ref.best_z, "nodes": ref.nodes_visited}
     # --- knapsack, sharded rounds ---

@@ -45,6 +45,11 @@ def test_world2_gloo_bnb_and_knapsack(tmp_path, lpx, oracle):
     # the work was actually split: neither rank solved every node alone
     tot = res[0]["bnb"]["lp_solves"] + res[1]["bnb"]["lp_solves"]
     assert res[0]["bnb"]["lp_solves"] < tot and res[1]["bnb"]["lp_solves"] < tot
+    # whole-job accounting: the replicated warm-up is counted once (by rank 0), so the sum over ranks cannot
+    # exceed what a single process visiting every node would count by more than the pruning differences allow
+    single = res[0]["bnb_single"]
+    assert single["z"] == res[0]["bnb"]["z"]
+    assert tot <= 2 * single["lp_solves"] + 8
 
 
 def test_single_process_level_search_with_seam_matches_oracle(lpx, oracle):
