@@ -123,6 +123,14 @@ private:
     EngineOptions opt;
 };
 
+class BranchAndBoundRevised : public ILPAlgorithm {     // Models/BranchAndBoundRevised.cs:17-390
+public:
+    explicit BranchAndBoundRevised(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
 class BranchAndBoundKnapsack : public ILPAlgorithm {    // Models/BranchAndBoundKnapsack.cs:12-548
 public:
     explicit BranchAndBoundKnapsack(const EngineOptions& o = {}) : opt(o) {}

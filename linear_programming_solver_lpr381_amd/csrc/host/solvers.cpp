@@ -407,6 +407,8 @@ SimplexResult LPSolver::Solve(const LPProblem& problem, const std::string& algor
     // not reachable through the reference's LPSolver (it is never instantiated there);
     // offered under its menu name so the knapsack path has an entry point
     else if (key == "branch and bound knapsack" || key == "knapsack") algo.reset(new BranchAndBoundKnapsack(opt));
+    // likewise never instantiated by the reference (Form1.cs:263-270 routes its menu entry to BranchAndBound)
+    else if (key == "revised branch and bound" || key == "branch and bound revised") algo.reset(new BranchAndBoundRevised(opt));
     else throw LpxException(LPX_E_UNKNOWN_ALGO, "Algorithm not supported: '" + algorithm + "'. Try one of: Primal Simplex, Revised Primal Simplex, Dual Simplex, Branch and Bound Simplex.");
     SimplexResult result = algo->Solve(problem, updatePivot);
     if (result.HasSolution && !result.Tableau.empty()) { FinalTableau = result.Tableau; FinalR = result.R; FinalC = result.C; HasFinalTableau = true; }

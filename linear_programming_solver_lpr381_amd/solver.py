@@ -201,6 +201,10 @@ class BranchAndBound(_Algo):            # Models/Branch&Bound.cs:20
     NAME = "Branch and Bound"
 
 
+class BranchAndBoundRevised(_Algo):     # Models/BranchAndBoundRevised.cs:17
+    NAME = "Revised Branch and Bound"
+
+
 class BranchAndBoundKnapsack(_Algo):    # Models/BranchAndBoundKnapsack.cs:12
     NAME = "Branch and Bound Knapsack"
 

@@ -166,6 +166,9 @@ enum {
 };
 void orc_bnb_result_free(orc_bnb_result* r);
 int orc_bnb_solve(const orc_problem* p, int mode, int max_iter, int64_t max_nodes, orc_bnb_result* out);
+/* BranchAndBoundRevised.Solve, Models/BranchAndBoundRevised.cs:27-98: same result record;
+ * node x*, z* quantised to 3 decimals by the reference's Summary-text round trip. */
+int orc_bnbr_solve(const orc_problem* p, int mode, int max_iter, int64_t max_nodes, orc_bnb_result* out);
 
 /* BranchAndBoundKnapsack.Solve, Models/BranchAndBoundKnapsack.cs:58-407 */
 typedef struct {

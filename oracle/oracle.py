@@ -97,6 +97,7 @@ def lib():
         L.orc_revised_result_free.restype = None
         L.orc_invert.argtypes = [_dp, C.c_int, _dp]
         L.orc_bnb_solve.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int64, C.POINTER(_BnbResult)]
+        L.orc_bnbr_solve.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int64, C.POINTER(_BnbResult)]
         L.orc_bnb_result_free.argtypes = [C.POINTER(_BnbResult)]
         L.orc_bnb_result_free.restype = None
         L.orc_knapsack_solve.argtypes = [C.POINTER(_Problem), C.c_int64, C.POINTER(_KnapResult)]
@@ -283,10 +284,10 @@ class BnbResult:
     log_z: np.ndarray
 
 
-def bnb_solve(p: Problem, mode: int = 0, max_iter: int = 10000, max_nodes: int = 0) -> BnbResult:
+def bnb_solve(p: Problem, mode: int = 0, max_iter: int = 10000, max_nodes: int = 0, revised: bool = False) -> BnbResult:
     r = _BnbResult()
     cp = p._c()
-    lib().orc_bnb_solve(C.byref(cp), mode, max_iter, max_nodes, C.byref(r))
+    (lib().orc_bnbr_solve if revised else lib().orc_bnb_solve)(C.byref(cp), mode, max_iter, max_nodes, C.byref(r))
     log = np.stack([_cp(r.log_depth, r.n_log, np.int32), _cp(r.log_outcome, r.n_log, np.int32),
                     _cp(r.log_branch_var, r.n_log, np.int32)], axis=1) if r.n_log else np.zeros((0, 3), np.int32)
     out = BnbResult(r.status, r.best_z, _cp(r.best_x, r.n, np.float64), bool(r.has_incumbent), r.lp_solves,

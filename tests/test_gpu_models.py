@@ -184,3 +184,33 @@ def test_kat8_knapsack_and_oracle_parity(gpu, oracle):
         assert r.OptimalValue == ref.best_z, n
         assert r.Nodes == ref.nodes_popped and r.Aux[0] == ref.relaxations and r.Aux[2] == ref.nodes_expanded
         assert r.Extra.astype(int).tolist() == ref.best_x.tolist()
+
+
+@pytest.mark.parametrize("mode,key", [(0, "faithful"), (1, "repaired")])
+def test_kat9_bnb_revised(gpu, mode, key):
+    """BranchAndBoundRevised -- node x*, z* re-parsed from the 3-decimal Summary text."""
+    k = KATS["kat9_bnb_revised"]
+    r = gpu.BranchAndBoundRevised(bnb_mode=mode).Solve(gpu.ParseFromText(k["text"]))
+    e = k[key]
+    assert r.OptimalValue == e["best_z"] and r.Extra.tolist() == e["best_x"] and r.LpSolves == e["lp_solves"]
+    assert r.NodeLog.tolist() == e["log"] and r.NodeZ.tolist() == e["log_z"]
+    assert r.Solution is None and r.Tableau is None        # text only, BranchAndBoundRevised.cs:92-96
+    assert r.Report == r.Summary and r.Report.startswith("Revised Branch & Bound Finished.\nBest integer z* = %g\n" % e["best_z"])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bnb_revised_identical_to_oracle_on_random_binary_ips(gpu, oracle, mode):
+    g = np.random.default_rng(29)
+    for trial in range(3):
+        n, m = 8, 4
+        A = g.integers(0, 10, size=(m, n)).astype(float)
+        b = np.floor(0.5 * A.sum(axis=1))
+        c = g.integers(1, 21, size=n).astype(float)
+        Af = np.vstack([A, np.eye(n)]); bf = np.concatenate([b, np.ones(n)])
+        p = gpu.LPProblem.from_arrays(0, c, Af, np.zeros(m + n, int), bf)
+        ref = oracle.bnb_solve(_oracle_problem(oracle, p), mode, revised=True)
+        r = gpu.BranchAndBoundRevised(bnb_mode=mode).Solve(p)
+        assert r.NodeLog.tolist() == ref.log.tolist(), trial
+        assert r.NodeZ.tolist() == ref.log_z.tolist() and r.LpSolves == ref.lp_solves
+        if ref.has_incumbent:
+            assert r.OptimalValue == ref.best_z and r.Extra.tolist() == ref.best_x.tolist()

@@ -251,3 +251,13 @@ def test_oracle_regression_against_committed_traces(oracle):
         rows, cols = synth.forced_pivot_list(e["R"], e["C"], e["count"], seed=7 + e["C"])
         chosen = oracle.forced_pivots(T, rows, cols, 0.1)
         assert chosen.tolist() == e["chosen"] and sha(T) == e["tableau_sha"]
+
+
+@pytest.mark.parametrize("mode,key", [(0, "faithful"), (1, "repaired")])
+def test_kat9_bnb_revised(oracle, mode, key):
+    k = KATS["kat9_bnb_revised"]
+    p, _ = oracle.parse_text(k["text"])
+    r = oracle.bnb_solve(p, mode, revised=True)
+    e = k[key]
+    assert r.best_z == e["best_z"] and r.best_x.tolist() == e["best_x"] and r.lp_solves == e["lp_solves"]
+    assert r.log.tolist() == e["log"] and r.log_z.tolist() == e["log_z"]
