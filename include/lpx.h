@@ -133,6 +133,25 @@ int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z);
 int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts, const int32_t* var,
                            const double* coef, const double* zero, const double* rhs);
 
+/* Warm start of a branch-and-bound child (NOT what the reference does -- it re-solves every
+ * node from the slack basis, Models/Branch&Bound.cs:148): `child` becomes `parent`'s final tableau plus the row
+ * of `x_var <= bound` (is_ge = 0) or `x_var >= bound` (is_ge = 1) written in the parent's basis, where
+ * `row_of_var` is the row in which x_var is basic.  The result is dual feasible; run it with lpx_dual_run /
+ * lpx_multi_run and fdf_guard = 0.  `child` needs capacity for the parent's shape + 1. */
+int lpx_tableau_build_child(lpx_tableau* child, lpx_tableau* parent, int var, int row_of_var, int is_ge, double bound);
+int lpx_tableau_basis(lpx_tableau* t, int32_t* basis /* [R-1] */);
+int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32_t* basis_out /* [R-1] or NULL */);
+/* Parent store: a solved node parks its final tableau in a slab slot (one D2D copy) and gives its handle
+ * back; its children are assembled from the slot.  Slots are sized for one capacity class (same Rcap/Ccap as
+ * the handles that use the store) and allocated 32 at a time. */
+typedef struct lpx_store lpx_store;
+int  lpx_store_create(int Rcap, int Ccap, lpx_store** out);
+void lpx_store_destroy(lpx_store* s);
+int  lpx_store_save(lpx_store* s, lpx_tableau* t, int* slot_out);
+int  lpx_store_release(lpx_store* s, int slot);
+int  lpx_tableau_build_child_from_store(lpx_tableau* child, lpx_store* s, int slot, int var, int row_of_var,
+                                        int is_ge, double bound);
+
 /* Branch-and-bound node batches: runs `count` independent tableaux to completion,
  * interleaving their batches on their own streams so that small node LPs overlap on one GPU.
  * dual[i] selects lpx_dual_run (1) or lpx_primal_run (0) semantics; statuses[i] gets each status. */
@@ -221,7 +240,8 @@ typedef struct lpx_solve_opts {
     int render_iterations; /* 1 = text callback receives the whole formatted tableau per pivot */
     int dual_flags;        /* 0 = faithful DualSimplex (defects D1/D2), 7 = repaired */
     int bnb_mode;          /* 0 = faithful, 1 = repaired */
-    int bnb_search;        /* 0 = reference DFS, 1 = level-synchronous sharded frontier */
+    int bnb_search;        /* 0 = reference DFS, 1 = level-synchronous sharded frontier (every node re-solved from the
+                              slack basis, as the reference), 2 = the same with warm-started children */
     int concurrent_nodes;  /* node LPs in flight per GPU (level search) */
     int rank, world;       /* shard of this process (level search / knapsack rounds) */
     int64_t max_nodes;     /* 0 = unlimited */

@@ -136,6 +136,15 @@ def lib() -> C.CDLL:
                                     PIVOT_CB, vp, C.POINTER(Stats)]
     L.lpx_tableau_solution.argtypes = [vp, C.c_int, dp, dp]
     L.lpx_tableau_set_shape.argtypes = [vp, C.c_int, C.c_int]
+    L.lpx_tableau_build_child.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.lpx_tableau_basis.argtypes = [vp, ip]
+    L.lpx_tableau_solution2.argtypes = [vp, C.c_int, dp, dp, ip]
+    L.lpx_store_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.lpx_store_destroy.argtypes = [vp]
+    L.lpx_store_destroy.restype = None
+    L.lpx_store_save.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    L.lpx_store_release.argtypes = [vp, C.c_int]
+    L.lpx_tableau_build_child_from_store.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
     L.lpx_tableau_build_node.argtypes = [vp, vp, C.c_int, ip, dp, dp, dp]
     L.lpx_multi_run.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),
                                 C.POINTER(C.c_int), C.POINTER(Stats)]

@@ -18,6 +18,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 
 namespace lpx { namespace host {
@@ -31,6 +34,15 @@ enum Outcome { O_ERROR = 0, O_INVALID = 1, O_INFEASIBLE_X = 2, O_PRUNED = 3, O_I
                O_BRANCHED = 6, O_DEPTH = 7, O_LP_INFEASIBLE = 8 };
 
 struct Cut { int var; Rel rel; double bound; };
+
+// LPX_BNB_TIMING=1: print where the host spends its time (diagnostic)
+struct PhaseTimer {
+    double build = 0, run = 0, collect = 0, decide = 0; bool on = false;
+    PhaseTimer() { const char* e = std::getenv("LPX_BNB_TIMING"); on = e && e[0] == '1'; }
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] build %.1f ms, run %.1f ms, collect %.1f ms, decide %.1f ms\n", build, run, collect, decide); }
+};
+static PhaseTimer g_pt;
 
 std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b; }
 
@@ -63,6 +75,10 @@ struct NodeLP {
     std::vector<double> T; int R = 0, C = 0; std::vector<int32_t> basis; bool dual = false;
     bool on_device = false; std::vector<int32_t> cvar; std::vector<double> ccoef, czero, crhs;
     lpx_tableau* h = nullptr;
+    // warm start: child of a parent whose final tableau is parked in a store slot
+    lpx_store* pstore = nullptr; int pslot = -1; int prow = -1; bool warm = false; bool keep = false;   // keep: park the result
+    lpx_store* kstore = nullptr; int kslot = -1; std::vector<int32_t> basis_out;
+    double wbound = 0.0; bool wis_ge = false; int wslot = 0; int depth = 0;
 };
 
 struct Ctx {
@@ -70,9 +86,21 @@ struct Ctx {
     double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
     SimplexResult* out; HandlePool pool; bool stop = false;
     bool count_work = true;      // false while this rank only mirrors the replicated warm-up of rank 0
+    std::vector<lpx_tableau*> released;
+    std::map<std::pair<int, int>, lpx_store*> stores;
+    lpx_store* store_for(lpx_tableau* h) {
+        const std::pair<int, int> cap = pool.cap_[h];
+        auto it = stores.find(cap);
+        if (it != stores.end()) return it->second;
+        lpx_store* s = nullptr;
+        int rc = lpx_store_create(cap.first, cap.second, &s);
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        stores[cap] = s;
+        return s;
+    }
     // resident root templates: the prepared root tableau as the primal / dual path builds it
     lpx_tableau* root_tpl[2] = {nullptr, nullptr}; int tplR[2] = {0, 0}, tplC[2] = {0, 0}; bool tpl_bad[2] = {false, false};
-    ~Ctx() { lpx_tableau_destroy(root_tpl[0]); lpx_tableau_destroy(root_tpl[1]); }
+    ~Ctx() { lpx_tableau_destroy(root_tpl[0]); lpx_tableau_destroy(root_tpl[1]); for (auto& kv : stores) lpx_store_destroy(kv.second); }
     void log(const std::string& s) { if (cb) cb(s + "\n", nullptr); }
 };
 
@@ -190,13 +218,21 @@ void prepare_device(Ctx& c, const std::vector<Cut>& cuts, NodeLP& lp)
     lp.on_device = true;
 }
 
+int cap_slack(int d) { const int s = (d + 31) / 32 * 32; return s > 0 ? s : 32; }
+
 void upload(Ctx& c, NodeLP& lp)
 {
+    if (lp.warm) {
+        const int d = lp.depth, w = lp.wslot;
+        lp.h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));
+        int rc = lpx_tableau_build_child_from_store(lp.h, lp.pstore, lp.pslot, lp.cvar.back(), lp.prow, lp.wis_ge ? 1 : 0, lp.wbound);
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        return;
+    }
     if (lp.on_device) {
         // capacity classes of 32 levels: one set of handles (and captured graphs) serves 32 depths
         const int d = (int)lp.cvar.size(), w = lp.dual ? 1 : 0;
-        const int capd = (d + 31) / 32 * 32 + (d % 32 == 0 && d > 0 ? 0 : 0);
-        const int slack = capd > 0 ? capd : 32;
+        const int slack = cap_slack(d);
         lp.h = c.pool.get(c.tplR[w] + slack, c.tplC[w] + slack);
         int rc = lpx_tableau_build_node(lp.h, c.root_tpl[lp.dual ? 1 : 0], (int)lp.cvar.size(), lp.cvar.data(),
                                         lp.ccoef.data(), lp.czero.data(), lp.crhs.data());
@@ -219,9 +255,15 @@ void collect(Ctx& c, NodeLP& lp, int status, const lpx_stats& st, int nvars)
     else if (lp.dual && c.opt.bnb_mode == 0) { lp.has_solution = false; }   // defect D2
     else {
         lp.x.assign(nvars, 0.0);
-        int rc = lpx_tableau_solution(lp.h, nvars, lp.x.data(), &lp.z);
+        lp.basis_out.assign(std::max(lp.R - 1, 1), 0);
+        int rc = lpx_tableau_solution2(lp.h, nvars, lp.x.data(), &lp.z, lp.keep ? lp.basis_out.data() : nullptr);
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         lp.has_solution = true;
+        if (lp.keep && status == LPX_OPTIMAL) {          // park the final tableau for the children
+            lp.kstore = c.store_for(lp.h);
+            rc = lpx_store_save(lp.kstore, lp.h, &lp.kslot);
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        }
     }
     c.pool.put(lp.h); lp.h = nullptr;
 }
@@ -232,6 +274,8 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     lpx_run_opts po, dopt; lpx_default_opts(&po, 0); lpx_default_opts(&dopt, 1);
     po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
+    bool any_warm = false; for (NodeLP* lp : group) if (lp->warm) any_warm = true;
+    if (any_warm) { dopt.fdf_guard = 0; dopt.cleanup = 1; }       // dual feasible start: only the dual loop (and its clean-up) runs
     if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
         for (NodeLP* lp : group) {
             if (c.count_work) c.out->LpSolves++;
@@ -253,15 +297,19 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         for (size_t i = a; i < b; ++i) {
             NodeLP* lp = group[i];
             if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
-            upload(c, *lp);
+            { const double t0 = PhaseTimer::now(); upload(c, *lp); g_pt.build += PhaseTimer::now() - t0; }
             hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
         }
         if (c.count_work) c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
         if (hs.empty()) continue;
         std::vector<int> st(hs.size()); std::vector<lpx_stats> ss(hs.size());
+        double t0 = PhaseTimer::now();
         int rc = lpx_multi_run(hs.data(), dual.data(), (int)hs.size(), &po, &dopt, st.data(), ss.data());
+        g_pt.run += PhaseTimer::now() - t0;
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        t0 = PhaseTimer::now();
         for (size_t i = 0; i < live.size(); ++i) collect(c, *live[i], st[i], ss[i], nvars);
+        g_pt.collect += PhaseTimer::now() - t0;
     }
 }
 
@@ -402,6 +450,106 @@ void LevelSearch(Ctx& c)
     }
 }
 
+// ---- search 2: level-synchronous frontier with WARM-STARTED children ----------------------
+// Not the reference's algorithm (it re-solves every node from the slack basis): a child starts from its
+// parent's final tableau plus the branching row written in the parent's basis, which is dual feasible, so only
+// the dual loop runs -- typically a handful of pivots instead of hundreds.  Same LP optimum per node, hence the
+// same B&B optimum; the optimal VERTEX of a degenerate node may differ from a cold solve, so node order and
+// counts are not comparable with searches 0/1.  Sharding and the per-level all-reduce are those of search 1.
+struct WNode { std::vector<Cut> cuts; int depth; lpx_store* store; int slot; int prow; };
+
+void WarmSearch(Ctx& c)
+{
+    const int world = std::max(1, c.opt.world), rank = c.opt.rank;
+    const size_t want = (size_t)world * 2;
+    bool replicated = world > 1;
+    c.count_work = !(replicated && rank != 0);
+    const bool root_dual = has_ge_or_eq(*c.root);
+    if (!ensure_template(c, root_dual)) return;
+    const int w = root_dual ? 1 : 0;
+    const int nvars = c.root->NumVars();
+    // a parked parent serves two children: release its slot when both are built
+    std::map<std::pair<lpx_store*, int>, int> refs;
+    auto row_of = [](const NodeLP& lp, int var) { for (size_t i = 0; i < lp.basis_out.size(); ++i) if (lp.basis_out[i] == var) return (int)i; return -1; };
+    auto add_children = [&](std::vector<WNode>& out, const std::vector<Cut>& cuts, int depth, const NodeLP& lp, int k, int fl, int ce) {
+        const int ik = row_of(lp, k);
+        if (ik < 0 || lp.kslot < 0) throw LpxException(LPX_EINVAL, "warm start: branching variable is not basic in the parked parent");
+        WNode up{cuts, depth + 1, lp.kstore, lp.kslot, ik}; up.cuts.push_back({k, Rel::GE, (double)ce});
+        WNode dn{cuts, depth + 1, lp.kstore, lp.kslot, ik}; dn.cuts.push_back({k, Rel::LE, (double)fl});
+        out.push_back(std::move(up)); out.push_back(std::move(dn));
+        refs[{lp.kstore, lp.kslot}] = 2;
+    };
+    auto unref = [&](lpx_store* s, int slot) { auto it = refs.find({s, slot}); if (it != refs.end() && --it->second == 0) { lpx_store_release(s, slot); refs.erase(it); } };
+
+    std::vector<WNode> frontier;
+    {   // root: cold solve, result parked
+        NodeLP lp; prepare_device(c, std::vector<Cut>{}, lp); lp.keep = true;
+        if (c.count_work) c.out->Nodes++;
+        std::vector<NodeLP*> g{&lp};
+        solve_group(c, g, nvars);
+        int fl = 0, ce = 0;
+        const std::vector<Cut> none;
+        int k = decide(c, none, lp, 0, "Root Problem", fl, ce);
+        if (k < 0) { if (lp.kslot >= 0) lpx_store_release(lp.kstore, lp.kslot); return; }
+        add_children(frontier, none, 0, lp, k, fl, ce);
+    }
+    for (;;) {
+        if (replicated && frontier.size() >= want) {
+            std::vector<WNode> mine;
+            for (size_t i = 0; i < frontier.size(); ++i) {
+                if ((int)(i % world) == rank) mine.push_back(std::move(frontier[i]));
+                else unref(frontier[i].store, frontier[i].slot);
+            }
+            frontier.swap(mine);
+            replicated = false;
+            c.count_work = true;
+        }
+        std::vector<NodeLP> lps(frontier.size());
+        std::vector<NodeLP*> group;
+        std::vector<char> skip(frontier.size(), 0);
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
+            if (c.count_work) c.out->Nodes++;
+            if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
+            NodeLP& lp = lps[i];
+            const Cut& k = frontier[i].cuts.back();
+            lp.warm = true; lp.dual = true; lp.keep = true; lp.wslot = w; lp.depth = frontier[i].depth;
+            lp.pstore = frontier[i].store; lp.pslot = frontier[i].slot; lp.prow = frontier[i].prow;
+            lp.cvar.push_back(k.var); lp.wis_ge = (k.rel == Rel::GE); lp.wbound = k.bound;
+            lp.R = c.tplR[w] + frontier[i].depth; lp.C = c.tplC[w] + frontier[i].depth;
+            group.push_back(&lp);
+        }
+        solve_group(c, group, nvars);
+        for (const WNode& f : frontier) unref(f.store, f.slot);          // every child of this level is built
+        std::vector<WNode> next;
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            if (skip[i] == 1) continue;
+            if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
+            int fl = 0, ce = 0;
+            const double t0 = PhaseTimer::now();
+            int k = decide(c, frontier[i].cuts, lps[i], frontier[i].depth, "Node", fl, ce);
+            g_pt.decide += PhaseTimer::now() - t0;
+            if (k < 0) { if (lps[i].kslot >= 0) lpx_store_release(lps[i].kstore, lps[i].kslot); continue; }
+            add_children(next, frontier[i].cuts, frontier[i].depth, lps[i], k, fl, ce);
+        }
+        frontier.swap(next);
+        double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
+        if (!replicated && world > 1 && c.opt.allreduce_max) {
+            const double mine = vals[0];
+            c.opt.allreduce_max(vals, 2);
+            if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); } }
+        }
+        if (vals[1] == 0.0) break;
+    }
+    if (world > 1 && c.opt.allreduce_max) {
+        double own = (c.has_best && !c.best_x.empty()) ? -(double)rank : -INFINITY;
+        c.opt.allreduce_max(&own, 1);
+        std::vector<double> xs(nvars, -INFINITY);
+        if (own == -(double)rank && c.has_best && !c.best_x.empty()) xs = c.best_x;
+        if (own != -INFINITY) { c.opt.allreduce_max(xs.data(), nvars); c.best_x = xs; }
+    }
+}
+
 }  // namespace
 
 // BranchAndBound.Solve, Models/Branch&Bound.cs:30-123
@@ -472,6 +620,8 @@ SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot update
     if (opt.bnb_search == 0) {
         std::vector<Cut> cuts;
         SolveNode(c, cuts, 0, "Root Problem");                                            // :95 (root solved a second time)
+    } else if (opt.bnb_search == 2 && !opt.test_node_lp && opt.bnb_mode == 1) {
+        WarmSearch(c);
     } else {
         LevelSearch(c);
     }

@@ -67,6 +67,8 @@ int select_mb_blocks(int C);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s);
 hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s);
 int update_blocks(int ld, int R);
+hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
+                              int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s);
 hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,
                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
                              int32_t* basis, hipStream_t s);

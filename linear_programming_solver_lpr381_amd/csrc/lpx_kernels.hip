@@ -498,34 +498,12 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
                                                    const int32_t* __restrict__ part_i, int nblk,
                                                    int forced, int ncw, int nunits)
 {
-    // Everything that does not depend on the state record is issued first: the tableau tile, the pivot-row
-    // slice and BOTH candidate factor columns (the parity that picks one is part of the state).  The state
-    // record is only needed to decide what to store.
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
-    const int cw = unit % ncw;
-    const int rb = unit / ncw;
-    const int col = cw * 128 + lane * 2;
-    const int row0 = rb * UPD_ROWS;
-    const bool live = (unit < nunits) && (col < ld) && (row0 < Rcap);
-    double* base = T + (size_t)row0 * ld + col;
-    double2 p = make_double2(0.0, 0.0);
-    double2 v[UPD_ROWS];
-    double f0[UPD_ROWS], f1[UPD_ROWS];
-    if (live) {
-        p = *reinterpret_cast<const double2*>(prow + col);
-#pragma unroll
-        for (int k = 0; k < UPD_ROWS; ++k) {
-            const int i = row0 + k;
-            if (i < Rcap) {
-                v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
-                f0[k] = fac0[i]; f1[k] = fac1[i];
-            }
-        }
-    }
+    // The state record is read FIRST: a launch that finds the loop finished (tail of a batch, finished node
+    // of a B&B group) must not stream the tableau.  (Issuing the tile loads ahead of it was measured: no gain
+    // on live launches, a full 16*R*C of wasted traffic on every dead one.)
     const int status = st->status;
     const int r = st->r;
+    const int lane = threadIdx.x & 63;
     const int R = shape ? shape[0] : Rcap, C = shape ? shape[1] : Ccap;
     if (status != LPX_RUNNING) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { us->status = status; us->iter = st->iter; }
@@ -549,20 +527,42 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
         us->status = LPX_RUNNING; us->iter = st->iter; us->qn = qn;
         us->primal_count = st->primal_count; us->forced_k = st->forced_k;
     }
-    if (r < 0 || !live || row0 >= R) return;             // skipped pivot / outside the live shape
+    if (r < 0) return;                                   // skipped pivot: nothing to update
     const int par = (st->iter - 1) & 1;
+    const double* __restrict__ fac = par ? fac1 : fac0;
     double* __restrict__ nxt = par ? fac0 : fac1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    if (unit >= nunits) return;
+    const int cw = unit % ncw;
+    const int rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    if (col >= ld) return;
+    const int row0 = rb * UPD_ROWS;
+    if (row0 >= R) return;                                // capacity-sized grid: rows beyond the live shape
+    const double2 p = *reinterpret_cast<const double2*>(prow + col);
+    double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);
     const bool wr = (((C - 1) & ~1) == col);
+
+    double2 v[UPD_ROWS];
+    double f[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R) {
+            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+            f[k] = fac[i];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < UPD_ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
             double2 o;
             if (i != r) {
-                const double f = par ? f1[k] : f0[k];
-                o.x = v[k].x - f * p.x;         // mul, then sub: contraction is off
-                o.y = v[k].y - f * p.y;
+                o.x = v[k].x - f[k] * p.x;      // mul, then sub: contraction is off
+                o.y = v[k].y - f[k] * p.y;
                 *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
             } else {
                 o = p;                          // row r already holds the normalised pivot row
@@ -646,6 +646,48 @@ __global__ __launch_bounds__(256) void lpx_build_node(const double* __restrict__
     }
     (void)d;
     T[(size_t)i * ld + j] = v;
+}
+
+// Warm start: the child of a solved node is the parent's FINAL tableau plus one branching
+// row expressed in the parent's basis.  With x_k basic in row ik:  `x_k <= f`  becomes  e_k - T[ik,:]  (rhs
+// f - x_k* < 0) and  `x_k >= c`  becomes  -e_k + T[ik,:]  (rhs -c + x_k* < 0); the new slack is basic in the new
+// row.  The objective row is unchanged, so the tableau stays dual feasible and only the dual loop has to run.
+__global__ __launch_bounds__(256) void lpx_build_child(const double* __restrict__ Tp, int ldp, int Rp, int Cp,
+                                                       const int32_t* __restrict__ basis_p,
+                                                       double* __restrict__ T, int ld, int var, int ik, int is_ge,
+                                                       double bound, int32_t* __restrict__ basis)
+{
+    const int mp = Rp - 1, R = Rp + 1, C = Cp + 1;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j == 0 && i < mp) basis[i] = basis_p[i];
+    if (j == 0 && i == mp) basis[mp] = Cp - 1;                      // the new slack column
+    if (j >= ld || i >= R) return;
+    double v = 0.0;
+    if (j < C) {
+        const int js = (j < Cp - 1) ? j : ((j == C - 1) ? Cp - 1 : -1);   // source column in the parent (-1: new slack)
+        if (i == mp) {                                              // the branching row
+            if (js < 0) v = 1.0;
+            else {
+                const double t = Tp[(size_t)ik * ldp + js];
+                const double e = (js == var) ? 1.0 : 0.0;
+                const double rhs = (js == Cp - 1) ? bound : 0.0;
+                v = is_ge ? ((-e - rhs) + t) : ((e + rhs) - t);     // GE: -e_k + row, rhs -c + x_k ; LE: e_k - row, rhs f - x_k
+            }
+        } else {
+            const int is = (i < mp) ? i : mp;                       // i == mp + 1 is the parent's objective row
+            v = (js < 0) ? 0.0 : Tp[(size_t)is * ldp + js];
+        }
+    }
+    T[(size_t)i * ld + j] = v;
+}
+
+hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
+                              int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_build_child, dim3((ld + 255) / 256, Rp + 1), dim3(256), 0, s, Tp, ldp, Rp, Cp, basis_p, T, ld,
+                       var, ik, is_ge, bound, basis);
+    return hipGetLastError();
 }
 
 hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,

@@ -587,7 +587,105 @@ int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts
     return 0;   // stream-ordered: the run that follows on node->stream sees the finished tableau
 }
 
-int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z)
+// ---- parent store: final tableaux of solved nodes parked in slab slots (warm-started B&B children) ----------
+struct lpx_store {
+    int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 32;
+    size_t slot_doubles = 0;                 // Rcap * ld
+    std::vector<double*> chunks_T; std::vector<int32_t*> chunks_b;
+    std::vector<int> R, C;                   // live shape per slot
+    std::vector<int> free_slots;
+};
+
+int lpx_store_create(int Rcap, int Ccap, lpx_store** out)
+{
+    if (!out || Rcap < 2 || Ccap < 2) { set_error("lpx_store_create: bad shape"); return LPX_EINVAL; }
+    int rc = ensure_device(); if (rc) return rc;
+    lpx_store* s = new lpx_store();
+    s->Rcap = Rcap; s->Ccap = Ccap; s->ld = (Ccap + 15) / 16 * 16;
+    s->slot_doubles = (size_t)Rcap * s->ld;
+    *out = s;
+    return 0;
+}
+
+void lpx_store_destroy(lpx_store* s)
+{
+    if (!s) return;
+    for (double* p : s->chunks_T) hipFree(p);
+    for (int32_t* p : s->chunks_b) hipFree(p);
+    delete s;
+}
+
+static double* store_T(lpx_store* s, int slot) { return s->chunks_T[slot / s->per_chunk] + (size_t)(slot % s->per_chunk) * s->slot_doubles; }
+static int32_t* store_b(lpx_store* s, int slot) { return s->chunks_b[slot / s->per_chunk] + (size_t)(slot % s->per_chunk) * s->Rcap; }
+
+int lpx_store_save(lpx_store* s, lpx_tableau* t, int* slot_out)
+{
+    if (!s || !t || !slot_out) { set_error("lpx_store_save: null argument"); return LPX_EINVAL; }
+    if (t->ld != s->ld || t->R > s->Rcap) { set_error("lpx_store_save: tableau does not match the store's capacity class"); return LPX_EINVAL; }
+    if (s->free_slots.empty()) {
+        double* Tc = nullptr; int32_t* bc = nullptr;
+        LPX_HIP_TRY(hipMalloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
+        hipError_t e = hipMalloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
+        if (e != hipSuccess) { hipFree(Tc); set_error("lpx_store_save: out of device memory"); return LPX_ENOMEM; }
+        const int base = (int)s->chunks_T.size() * s->per_chunk;
+        s->chunks_T.push_back(Tc); s->chunks_b.push_back(bc);
+        s->R.resize(base + s->per_chunk, 0); s->C.resize(base + s->per_chunk, 0);
+        for (int k = s->per_chunk - 1; k >= 0; --k) s->free_slots.push_back(base + k);
+    }
+    const int slot = s->free_slots.back(); s->free_slots.pop_back();
+    LPX_HIP_TRY(hipMemcpyAsync(store_T(s, slot), t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipMemcpyAsync(store_b(s, slot), t->basis, sizeof(int32_t) * (t->R - 1), hipMemcpyDeviceToDevice, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));       // the handle may be reused by the caller right away
+    s->R[slot] = t->R; s->C[slot] = t->C;
+    *slot_out = slot;
+    return 0;
+}
+
+int lpx_store_release(lpx_store* s, int slot)
+{
+    if (!s || slot < 0 || slot >= (int)s->R.size()) return LPX_EINVAL;
+    s->free_slots.push_back(slot);
+    return 0;
+}
+
+int lpx_tableau_build_child_from_store(lpx_tableau* child, lpx_store* s, int slot, int var, int row_of_var, int is_ge, double bound)
+{
+    if (!child || !s || slot < 0 || slot >= (int)s->R.size()) { set_error("lpx_tableau_build_child_from_store: bad argument"); return LPX_EINVAL; }
+    const int Rp = s->R[slot], Cp = s->C[slot];
+    if (var < 0 || var >= Cp - 1 || row_of_var < 0 || row_of_var >= Rp - 1) { set_error("lpx_tableau_build_child_from_store: variable / row out of range"); return LPX_EINVAL; }
+    if (Rp + 1 > child->Rcap || Cp + 1 > child->Ccap) { set_error("lpx_tableau_build_child_from_store: child handle too small"); return LPX_EINVAL; }
+    { int rc = lpx_tableau_set_shape(child, Rp + 1, Cp + 1); if (rc) return rc; }
+    LPX_HIP_TRY(launch_build_child(store_T(s, slot), s->ld, Rp, Cp, store_b(s, slot), child->T, child->ld,
+                                   var, row_of_var, is_ge ? 1 : 0, bound, child->basis, child->stream));
+    LPX_HIP_TRY(hipMemsetAsync(child->st, 0, sizeof(DevState), child->stream));
+    return 0;
+}
+
+int lpx_tableau_build_child(lpx_tableau* child, lpx_tableau* parent, int var, int row_of_var, int is_ge, double bound)
+{
+    if (!child || !parent || child == parent) { set_error("lpx_tableau_build_child: bad argument"); return LPX_EINVAL; }
+    if (var < 0 || var >= parent->C - 1 || row_of_var < 0 || row_of_var >= parent->R - 1) { set_error("lpx_tableau_build_child: variable / row out of range"); return LPX_EINVAL; }
+    if (parent->R + 1 > child->Rcap || parent->C + 1 > child->Ccap) { set_error("lpx_tableau_build_child: child handle too small"); return LPX_EINVAL; }
+    LPX_HIP_TRY(hipStreamSynchronize(parent->stream));              // the parent's final tableau must be complete
+    { int rc = lpx_tableau_set_shape(child, parent->R + 1, parent->C + 1); if (rc) return rc; }
+    LPX_HIP_TRY(launch_build_child(parent->T, parent->ld, parent->R, parent->C, parent->basis, child->T, child->ld,
+                                   var, row_of_var, is_ge ? 1 : 0, bound, child->basis, child->stream));
+    LPX_HIP_TRY(hipMemsetAsync(child->st, 0, sizeof(DevState), child->stream));
+    return 0;
+}
+
+int lpx_tableau_basis(lpx_tableau* t, int32_t* basis)
+{
+    if (!t || !basis) return LPX_EINVAL;
+    if (t->R > 1) LPX_HIP_TRY(hipMemcpyAsync(basis, t->basis, sizeof(int32_t) * (t->R - 1), hipMemcpyDeviceToHost, t->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32_t* basis_out);
+int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z) { return lpx_tableau_solution2(t, nvars, x, z, nullptr); }
+
+int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32_t* basis_out)
 {
     if (!t || nvars < 0) { set_error("lpx_tableau_solution: bad argument"); return LPX_EINVAL; }
     const int m = t->R - 1;
@@ -602,6 +700,7 @@ int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z)
         for (int i = 0; i < m; ++i) if (basis[i] >= 0 && basis[i] < nvars) x[basis[i]] = rhs[i];   // FinalizeReport :135-136
     }
     if (z) *z = rhs[m];                                                                           // :138
+    if (basis_out && m > 0) std::memcpy(basis_out, basis.data(), sizeof(int32_t) * m);
     return 0;
 }
 

@@ -214,3 +214,30 @@ def test_bnb_revised_identical_to_oracle_on_random_binary_ips(gpu, oracle, mode)
         assert r.NodeZ.tolist() == ref.log_z.tolist() and r.LpSolves == ref.lp_solves
         if ref.has_incumbent:
             assert r.OptimalValue == ref.best_z and r.Extra.tolist() == ref.best_x.tolist()
+
+
+def test_bnb_warm_started_children_reach_the_same_optimum(gpu, oracle):
+    """SURVEY 8f rank 3 (bnb_search=2): children start from the parent's final tableau + the branching row and
+    run the dual loop only.  Same LP optimum per node -> same B&B optimum as the reference-order search; node
+    z of the root's two children must equal the cold re-solve to 1e-9 (they are the same LPs)."""
+    g = np.random.default_rng(41)
+    for trial in range(5):
+        n, m = 12, 5
+        A = g.integers(0, 10, size=(m, n)).astype(float)
+        b = np.floor(0.5 * A.sum(axis=1))
+        c = g.integers(1, 21, size=n).astype(float)
+        Af = np.vstack([A, np.eye(n)]); bf = np.concatenate([b, np.ones(n)])
+        p = gpu.LPProblem.from_arrays(0, c, Af, np.zeros(m + n, int), bf)
+        ref = oracle.bnb_solve(_oracle_problem(oracle, p), 1)
+        cold = gpu.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=4).Solve(p)
+        warm = gpu.BranchAndBound(bnb_mode=1, bnb_search=2, concurrent_nodes=4).Solve(p)
+        assert cold.OptimalValue == ref.best_z, trial
+        assert abs(warm.OptimalValue - ref.best_z) <= 1e-9 * abs(ref.best_z), trial     # different pivot path, same optimum
+        assert abs(np.asarray(warm.Solution) @ c - ref.best_z) <= 1e-9 * abs(ref.best_z)
+        # level order: entry 0 = root, entries 1,2 = its ceil / floor children in both searches
+        if len(cold.NodeZ) >= 3 and len(warm.NodeZ) >= 3:
+            for a, bz in zip(cold.NodeZ[:3], warm.NodeZ[:3]):
+                assert abs(a - bz) <= 1e-9 * max(1.0, abs(a))
+            assert cold.NodeLog[:3].tolist() == warm.NodeLog[:3].tolist()
+        # and it needs far fewer pivots
+        assert warm.Stats["pivots"] <= cold.Stats["pivots"]
