@@ -167,7 +167,7 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
     int win = -1;
     LPX_HS_BEGIN
     for (int seg = 0; seg < L; seg += 64 * WH_PER) {
-        decltype(src.den(0)) den[WH_PER]; double num[WH_PER], rt[WH_PER];
+        double den[WH_PER], num[WH_PER], rt[WH_PER];
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) {
             // clamped index instead of a guard: a guarded load becomes its own exec-masked branch with
@@ -253,15 +253,6 @@ struct RowRatio {
     __device__ __forceinline__ double den(int i) const { return col[(size_t)i * cs]; }
     __device__ __forceinline__ double num(int i) const { return rhs[(size_t)i * rs]; }
     __device__ __forceinline__ double value(double a, double b) const { return a > eps ? b / a : __builtin_inf(); }
-};
-// rows, with the factor column living in one of two ping-pong buffers chosen by a parity that is itself
-// still in flight: both candidates are loaded (den is a pair) so the loads do not wait for the state record
-struct RowRatioPP {
-    const double* c0; const double* c1; const double* rhs; double eps; int par;
-    struct Den { double a0, a1; };
-    __device__ __forceinline__ Den den(int i) const { Den d; d.a0 = c0[i]; d.a1 = c1[i]; return d; }
-    __device__ __forceinline__ double num(int i) const { return rhs[i]; }
-    __device__ __forceinline__ double value(Den d, double b) const { const double a = par ? d.a1 : d.a0; return a > eps ? b / a : __builtin_inf(); }
 };
 // columns of the dual loop: den = T[r,j], num = T[m,j], eligible den < -eps, ratio = num/(-den)
 //       (Models/DualSimplex.cs:79-91)

@@ -437,7 +437,7 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
         if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
         else if (q < 0) final_status = LPX_OPTIMAL;
         else {
-            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatioPP{P.col0, P.col1, P.rhsbuf, P.eps, iter & 1});   // every wave, no barrier
+            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps});   // every wave, no barrier
             if (r < 0) final_status = LPX_UNBOUNDED;
             scanrow = m;
         }
