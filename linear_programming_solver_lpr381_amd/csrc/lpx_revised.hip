@@ -39,6 +39,30 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// dot of two length-m vectors by one wave: 16-byte loads, four independent 1-KiB chunks in flight per
+// operand and four accumulator pairs (a fixed, deterministic summation order; the revised path is compared
+// on pivots and 1e-9 objective, not bitwise).  Both vectors are padded to a multiple of 16 doubles.
+__device__ __forceinline__ double wave_dot(const double* __restrict__ x, const double* __restrict__ y, int m, int lane)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    const int mp = m & ~1;
+    int k = lane * 2;
+    for (; k + 384 < mp; k += 512) {
+        const double2 x0 = *reinterpret_cast<const double2*>(x + k),       y0 = *reinterpret_cast<const double2*>(y + k);
+        const double2 x1 = *reinterpret_cast<const double2*>(x + k + 128), y1 = *reinterpret_cast<const double2*>(y + k + 128);
+        const double2 x2 = *reinterpret_cast<const double2*>(x + k + 256), y2 = *reinterpret_cast<const double2*>(y + k + 256);
+        const double2 x3 = *reinterpret_cast<const double2*>(x + k + 384), y3 = *reinterpret_cast<const double2*>(y + k + 384);
+        s0 += x0.x * y0.x; s1 += x0.y * y0.y; s2 += x1.x * y1.x; s3 += x1.y * y1.y;
+        s4 += x2.x * y2.x; s5 += x2.y * y2.y; s6 += x3.x * y3.x; s7 += x3.y * y3.y;
+    }
+    for (; k < mp; k += 128) {
+        const double2 xv = *reinterpret_cast<const double2*>(x + k), yv = *reinterpret_cast<const double2*>(y + k);
+        s0 += xv.x * yv.x; s1 += xv.y * yv.y;
+    }
+    if ((m & 1) && lane == 0) s0 += x[m - 1] * y[m - 1];
+    return wave_sum(((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)));
+}
+
 // A (m x n, packed) -> AT (n x ldat): 32x32 tiles through LDS.
 __global__ __launch_bounds__(256) void rv_transpose(const double* __restrict__ A, int m, int n,
                                                     double* __restrict__ AT, int ldat)
@@ -68,16 +92,7 @@ __global__ __launch_bounds__(256) void rv_price_dot(RvParams P)
     if (P.key[j] < 0) { if (lane == 0) P.rc[j] = __builtin_inf(); return; }
     const double* __restrict__ a = P.AT + (size_t)j * P.ldat;
     const double* __restrict__ pi = P.W + (size_t)P.m * P.ldw;
-    double s0 = 0.0, s1 = 0.0;
-    const int mp = P.m & ~1;
-    for (int k = lane * 2; k < mp; k += 128) {
-        const double2 av = *reinterpret_cast<const double2*>(a + k);
-        const double2 pv = *reinterpret_cast<const double2*>(pi + k);
-        s0 += av.x * pv.x;
-        s1 += av.y * pv.y;
-    }
-    if ((P.m & 1) && lane == 0) s0 += a[P.m - 1] * pi[P.m - 1];
-    const double s = wave_sum(s0 + s1);
+    const double s = wave_dot(a, pi, P.m, lane);
     if (lane == 0) P.rc[j] = P.c[j] - s;
 }
 
@@ -144,16 +159,7 @@ __global__ __launch_bounds__(256) void rv_ftran(RvParams P)
     if (i >= P.m) return;
     const double* __restrict__ w = P.W + (size_t)i * P.ldw;
     const double* __restrict__ a = P.aq;
-    double s0 = 0.0, s1 = 0.0;
-    const int mp = P.m & ~1;
-    for (int k = lane * 2; k < mp; k += 128) {
-        const double2 wv = *reinterpret_cast<const double2*>(w + k);
-        const double2 av = *reinterpret_cast<const double2*>(a + k);
-        s0 += wv.x * av.x;
-        s1 += wv.y * av.y;
-    }
-    if ((P.m & 1) && lane == 0) s0 += w[P.m - 1] * a[P.m - 1];
-    const double s = wave_sum(s0 + s1);
+    const double s = wave_dot(w, a, P.m, lane);
     if (lane == 0) P.fac[i] = s;
 }
 
