@@ -38,6 +38,22 @@ METRIC = "simplex pivots/sec on dense m×n tableau; B&B nodes/sec at 1/2/4/8 GPU
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def rocprof_kernel_us(R, C, kernel="lpx::lpx_update_mb"):
+    """Mean duration of the update kernel at this shape from the committed rocprofv3 --kernel-trace of this
+    same script (profiles/r01_f_kernel_by_shape.json, tools/trace_by_shape.py) -- the cross-check of the
+    HIP-event figure measured live below (events bracket the dispatch and read ~1.5 us longer on the 8 us
+    kernel, ~1 % on the 80 us one)."""
+    path = os.path.join(ROOT, "profiles", "r01_f_kernel_by_shape.json")
+    if not os.path.exists(path):
+        return None
+    ld = (C + 15) // 16 * 16
+    units = ((ld + 127) // 128) * ((R + 7) // 8)
+    grid = ((units + 3) // 4) * 256
+    d = json.load(open(path))
+    e = d.get(f"{kernel}@grid{grid}x1")
+    return e["mean_ns_live"] / 1e3 if e else None
+
+
 def pmc_traffic(R, C):
     """HBM bytes per launch of the update kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE in separate runs of tools/k4_headline.py, FETCH doubled per the gfx950
@@ -237,7 +253,8 @@ def main():
         ach = alg / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"kernel": "lpx_update_mb", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(R, C),
-                           "avg_kernel_us": 1e3 * k_ms, "launches": pst["update_launches"],
+                           "avg_kernel_us": 1e3 * k_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(R, C),
+                           "launches": pst["update_launches"],
                            "algorithmic_bytes_per_launch": alg,
                            "note": "25 MB tableau: resident in the 256 MiB Infinity Cache, not an HBM stream; "
                                    "see roofline_headline for the HBM-streaming shape"}
@@ -256,7 +273,8 @@ def main():
         out["roofline_headline"] = {"kernel": "lpx_update_mb", "shape": [HR, HC], "bound": "hbm",
                                     "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": hach / HBM_PEAK_GBS, "traffic": pmc_traffic(HR, HC),
-                                    "avg_kernel_us": 1e3 * hk_ms, "launches": hst["update_launches"],
+                                    "avg_kernel_us": 1e3 * hk_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(HR, HC),
+                                    "launches": hst["update_launches"],
                                     "algorithmic_bytes_per_launch": halg,
                                     "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}
         hd.close()
