@@ -263,6 +263,8 @@ typedef struct lpx_solve_opts {
                            const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
                            double* frac_val);
     void* test_user;
+    int bnb_dive;          /* sharded searches: 0 = whole frontier per round (breadth first), 1 = only the deepest
+                              `concurrent_nodes` nodes of the pool per round (depth-first-K: reaches incumbents early) */
 } lpx_solve_opts;
 
 typedef struct lpx_result {                        /* SimplexResult, Models/PrimalSimplex.cs:38-49 */

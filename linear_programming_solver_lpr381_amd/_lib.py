@@ -61,7 +61,8 @@ class SolveOpts(C.Structure):
                 ("concurrent_nodes", C.c_int), ("rank", C.c_int), ("world", C.c_int),
                 ("max_nodes", C.c_int64), ("allreduce_max", ALLREDUCE_CB), ("allreduce_user", C.c_void_p),
                 ("text_cb", TEXT_CB), ("text_user", C.c_void_p),
-                ("test_node_lp", TEST_NODE_LP), ("test_knap_relax", TEST_KNAP_RELAX), ("test_user", C.c_void_p)]
+                ("test_node_lp", TEST_NODE_LP), ("test_knap_relax", TEST_KNAP_RELAX), ("test_user", C.c_void_p),
+                ("bnb_dive", C.c_int)]
 
 
 class Result(C.Structure):

@@ -405,6 +405,14 @@ void LevelSearch(Ctx& c)
             replicated = false;
             c.count_work = true;
         }
+        // this round's nodes: the whole frontier (breadth first) or, with bnb_dive, its deepest K nodes
+        std::vector<FNode> parked;
+        if (c.opt.bnb_dive && !replicated && frontier.size() > (size_t)std::max(1, c.opt.concurrent_nodes)) {
+            std::stable_sort(frontier.begin(), frontier.end(), [](const FNode& a, const FNode& b) { return a.depth > b.depth; });
+            const size_t K = (size_t)std::max(1, c.opt.concurrent_nodes);
+            parked.assign(std::make_move_iterator(frontier.begin() + K), std::make_move_iterator(frontier.end()));
+            frontier.resize(K);
+        }
         // solve this level
         std::vector<NodeLP> lps(frontier.size());
         std::vector<NodeLP*> group;
@@ -430,6 +438,7 @@ void LevelSearch(Ctx& c)
             next.push_back(std::move(dn));
         }
         frontier.swap(next);
+        for (FNode& f : parked) frontier.push_back(std::move(f));
         // one all-reduce(max) per level: incumbent bound and "someone still has work"
         double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
         if (!replicated && world > 1 && c.opt.allreduce_max) {
@@ -504,6 +513,13 @@ void WarmSearch(Ctx& c)
             replicated = false;
             c.count_work = true;
         }
+        std::vector<WNode> parked;
+        if (c.opt.bnb_dive && !replicated && frontier.size() > (size_t)std::max(1, c.opt.concurrent_nodes)) {
+            std::stable_sort(frontier.begin(), frontier.end(), [](const WNode& a, const WNode& b) { return a.depth > b.depth; });
+            const size_t K = (size_t)std::max(1, c.opt.concurrent_nodes);
+            parked.assign(std::make_move_iterator(frontier.begin() + K), std::make_move_iterator(frontier.end()));
+            frontier.resize(K);
+        }
         std::vector<NodeLP> lps(frontier.size());
         std::vector<NodeLP*> group;
         std::vector<char> skip(frontier.size(), 0);
@@ -533,6 +549,7 @@ void WarmSearch(Ctx& c)
             add_children(next, frontier[i].cuts, frontier[i].depth, lps[i], k, fl, ce);
         }
         frontier.swap(next);
+        for (WNode& f : parked) frontier.push_back(std::move(f));
         double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
         if (!replicated && world > 1 && c.opt.allreduce_max) {
             const double mine = vals[0];

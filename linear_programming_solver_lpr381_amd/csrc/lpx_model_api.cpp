@@ -54,6 +54,7 @@ int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts*
     e.dual_flags = o->dual_flags; e.bnb_mode = o->bnb_mode; e.bnb_search = o->bnb_search;
     e.concurrent_nodes = o->concurrent_nodes > 0 ? o->concurrent_nodes : 1;
     e.rank = o->rank; e.world = o->world > 0 ? o->world : 1; e.max_nodes = o->max_nodes;
+    e.bnb_dive = o->bnb_dive;
     if (o->allreduce_max) {
         auto fn = o->allreduce_max; void* u = o->allreduce_user;
         e.allreduce_max = [fn, u](double* v, int n) { fn(u, v, n); };

@@ -68,7 +68,8 @@ def test_single_process_level_search_with_seam_matches_oracle(lpx, oracle):
         dfs = lpx.BranchAndBound(bnb_mode=mode, bnb_search=0, test_node_lp=node_lp).Solve(p)
         assert dfs.NodeLog.tolist() == ref.log.tolist() and dfs.LpSolves == ref.lp_solves
         lvl = lpx.BranchAndBound(bnb_mode=mode, bnb_search=1, concurrent_nodes=3, test_node_lp=node_lp).Solve(p)
+        dive = lpx.BranchAndBound(bnb_mode=mode, bnb_search=1, bnb_dive=1, concurrent_nodes=2, test_node_lp=node_lp).Solve(p)
         if ref.has_incumbent:
             assert dfs.OptimalValue == ref.best_z
             if mode == 1:
-                assert lvl.OptimalValue == ref.best_z
+                assert lvl.OptimalValue == ref.best_z and dive.OptimalValue == ref.best_z

@@ -241,3 +241,20 @@ def test_bnb_warm_started_children_reach_the_same_optimum(gpu, oracle):
             assert cold.NodeLog[:3].tolist() == warm.NodeLog[:3].tolist()
         # and it needs far fewer pivots
         assert warm.Stats["pivots"] <= cold.Stats["pivots"]
+
+
+@pytest.mark.parametrize("search", [1, 2])
+def test_bnb_dive_policy_reaches_the_same_optimum(gpu, oracle, search):
+    """bnb_dive=1: each round takes the deepest K nodes of the pool (depth-first-K) -- same optimum."""
+    g = np.random.default_rng(43)
+    for trial in range(4):
+        n, m = 12, 5
+        A = g.integers(0, 10, size=(m, n)).astype(float)
+        b = np.floor(0.5 * A.sum(axis=1))
+        c = g.integers(1, 21, size=n).astype(float)
+        Af = np.vstack([A, np.eye(n)]); bf = np.concatenate([b, np.ones(n)])
+        p = gpu.LPProblem.from_arrays(0, c, Af, np.zeros(m + n, int), bf)
+        ref = oracle.bnb_solve(_oracle_problem(oracle, p), 1)
+        r = gpu.BranchAndBound(bnb_mode=1, bnb_search=search, bnb_dive=1, concurrent_nodes=3).Solve(p)
+        assert abs(r.OptimalValue - ref.best_z) <= 1e-9 * abs(ref.best_z), (search, trial)
+        assert abs(np.asarray(r.Solution) @ c - ref.best_z) <= 1e-9 * abs(ref.best_z)

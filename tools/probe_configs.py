@@ -17,11 +17,11 @@ if "rev" in which:
 if "bnb" in which or "wide" in which:
     c, A, rel, b = synth.binary_ip(512, 256)
     p = L.LPProblem.from_arrays(0, c, A, rel, b)
-    for (mode, search, cn, mx) in ([(0, 0, 1, 16), (1, 0, 1, 12), (1, 1, 4, 24), (1, 1, 8, 48)] if 'wide' not in which else [(1, 2, 64, 1600)]):
+    for (mode, search, cn, mx) in ([(0, 0, 1, 16), (1, 0, 1, 12), (1, 1, 4, 24), (1, 1, 8, 48)] if 'wide' not in which else [(1, 2, 64, 1600)] if 'dive' not in which else [(1, 2, 64, 20000), (1, 1, 32, 1500)]):
         t = time.perf_counter()
-        r = L.BranchAndBound(bnb_mode=mode, bnb_search=search, concurrent_nodes=cn, max_nodes=mx).Solve(p)
+        r = L.BranchAndBound(bnb_mode=mode, bnb_search=search, concurrent_nodes=cn, max_nodes=mx, bnb_dive=1 if "dive" in which else 0).Solve(p)
         dt = time.perf_counter() - t
-        print(f"bnb mode={mode} search={search} conc={cn}: nodes={r.Nodes} lp_solves={r.LpSolves} pivots={r.Stats['pivots']} best={r.OptimalValue} {dt:.2f}s -> {r.LpSolves/dt:.1f} LP/s, {r.Stats['pivots']/dt:.0f} pivots/s")
+        print(f"bnb mode={mode} search={search} conc={cn} depth={int(r.NodeLog[:,0].max()) if len(r.NodeLog) else 0}: nodes={r.Nodes} lp_solves={r.LpSolves} pivots={r.Stats['pivots']} best={r.OptimalValue} {dt:.2f}s -> {r.LpSolves/dt:.1f} LP/s, {r.Stats['pivots']/dt:.0f} pivots/s")
 if "knap" in which:
     p, w, cap = synth.knapsack(100000)
     kp = L.LPProblem(L.Sense.Max, p.tolist(), [L.Constraint(w.tolist(), L.Rel.LE, cap)])
