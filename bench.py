@@ -244,6 +244,20 @@ def main():
                            "relaxations_per_s": rel_total / tk_max, "wall_s": tk_max, "incumbent": rk.OptimalValue}
 
     if rank == 0 and not args.no_extras:
+        # ---- measured device-to-device copy bandwidth of THIS box (report both peaks) ------
+        src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
         # ---- roofline of the rank-1 update kernel on this workload (profile pass) ---------------------
         popts = L.default_opts(False, batch=args.batch, profile=1)
         dt.restore()
@@ -253,6 +267,7 @@ def main():
         ach = alg / (k_ms * 1e-3) / 1e9
         out["roofline"] = {"kernel": "lpx_update_mb", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(R, C),
+                           "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": ach / copy_gbs,
                            "avg_kernel_us": 1e3 * k_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(R, C),
                            "launches": pst["update_launches"],
                            "algorithmic_bytes_per_launch": alg,
@@ -273,6 +288,7 @@ def main():
         out["roofline_headline"] = {"kernel": "lpx_update_mb", "shape": [HR, HC], "bound": "hbm",
                                     "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": hach / HBM_PEAK_GBS, "traffic": pmc_traffic(HR, HC),
+                                    "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": hach / copy_gbs,
                                     "avg_kernel_us": 1e3 * hk_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(HR, HC),
                                     "launches": hst["update_launches"],
                                     "algorithmic_bytes_per_launch": halg,
@@ -309,6 +325,25 @@ def main():
             out["cpu_baseline"] = {"value": len(tr_c) / cpu_s, "unit": "pivots/s", "cores": 1, "kind": "port",
                                    "sample": f"all {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
                                              f"(gcc -O2 -ffp-contract=off, scalar), {cpu_s:.1f} s"}
+            # courtesy strong baseline: the same loop with Pivot's rows spread over all host cores
+            ncores = len(os.sched_getaffinity(0))
+            Tm, bm = T.copy(), basis.copy()
+            t2 = time.perf_counter()
+            st_m, tr_m = O.primal_tableau(Tm, bm, max_iter=args.cpu_sample_pivots, threads=ncores)
+            mt_s = time.perf_counter() - t2
+            assert np.array_equal(tr_m, tr_c) and np.array_equal(Tm, Tc)
+            out["cpu_baseline"]["all_cores"] = {"value": len(tr_m) / mt_s, "unit": "pivots/s", "cores": ncores,
+                                                "sample": f"same {len(tr_m)} pivots, oracle/primal_mt.c (OpenMP over "
+                                                          f"the rows of Pivot, bit-identical), {mt_s:.1f} s"}
+            # reference-faithful revised path (Invert every iteration), bounded: 3 iterations at m=1024
+            c1, A1, b1 = synth.dense_lp(1024, 2048)
+            t2 = time.perf_counter()
+            rr_c = O.revised_solve(O.Problem(O.MAX, c1, A1, np.zeros(1024, np.int32), b1), max_iter=3)
+            cr = time.perf_counter() - t2
+            out["cpu_baseline"]["revised_iterations_per_s_m1024"] = len(rr_c.trace) / cr
+            out["cpu_baseline"]["revised_sample"] = (f"first {len(rr_c.trace)} iterations at m=1024 n=2048, oracle/revised.c "
+                                                     f"(full Invert per iteration as the reference), {cr:.1f} s; "
+                                                     "config 3 (m=4096) costs 64x the flops per iteration -- extrapolation, not measured")
             # bounded CPU samples of the other legs, for the record
             t2 = time.perf_counter()
             rk_c = O.knapsack_solve(O.Problem(O.MAX, pk, wk.reshape(1, -1), [O.LE], [capk]), max_nodes=4000)

@@ -34,6 +34,11 @@ enum {
     LPX_INFEASIBLE = 2,   /* "INFEASIBLE" Models/DualSimplex.cs:92-96 */
     LPX_ITER_LIMIT = 3,   /* exception "Iteration limit exceeded." Models/PrimalSimplex.cs:95-96 */
     LPX_RUNNING    = 4,   /* internal: loop not finished */
+    /* outcomes of the cutting-plane consumers (lpx_result.status for "Cutting Plane" / "Revised Cutting Plane") */
+    LPX_CUT_INTEGER     = 0,  /* "Status: OPTIMAL INTEGER" Models/CuttingPlane.cs:91-104, CuttingPlaneRevised.cs:49-57 */
+    LPX_CUT_INCOMPLETE  = 10, /* 50 iterations used up, Models/CuttingPlane.cs:132-137, CuttingPlaneRevised.cs:70-77 */
+    LPX_CUT_ERROR       = 11, /* "Error: ..." summaries, Models/CuttingPlane.cs:42-74,116-124 */
+    LPX_CUT_NOT_OPTIMAL = 12, /* Models/CuttingPlaneRevised.cs:27-35 */
     LPX_EINVAL     = -1,
     LPX_EDEVICE    = -2,  /* no usable gfx950 device / HIP failure */
     LPX_ENOMEM     = -3,
@@ -189,6 +194,11 @@ int  lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, voi
 /* Bidx[m]; Nidx[n] in the reference's list order; xB[m]; *z = c_B . x_B of the minimised model. */
 int  lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB, double* z);
 int  lpx_revised_binv(lpx_revised* r, double* Binv /* [m*m] row-major */);
+/* What the reference prints per iteration (BuildIterationBlock, Models/RevisedPrimalSimplex.cs:191-246), as
+ * left by the LAST completed iteration: rc[n+m] = reduced cost of every column as priced at its start
+ * (+inf for columns that were basic then; rN of :71 is rc gathered in that iteration's Nidx order) and
+ * d[m] = B^-1 a_entering (:96).  theta* (:105) equals xB[leaveRow] after the update.  Either may be NULL. */
+int  lpx_revised_iteration_view(lpx_revised* r, double* rc, double* d);
 /* K7': recompute [[B^-1, x_B], [c_B B^-1, z]] from the current basis with the device Gauss-Jordan below
  * (what the reference does every iteration, :128-133).  lpx_revised_set_refactor(r, k) makes
  * lpx_revised_run do it after every k iterations (0 = never, the default). */
@@ -281,6 +291,7 @@ typedef struct lpx_result {                        /* SimplexResult, Models/Prim
     double* node_z;                 /* [n_log] */
     double aux[4];                  /* revised: {z_original, z_internal}; knapsack: {relaxations, popped, expanded, max_heap} */
     lpx_stats stats;
+    int n_cuts; double* cuts;       /* cutting plane: [n_cuts*(nvars+1)] = (A[0..nvars), B) per cut, in the order added */
 } lpx_result;
 
 void lpx_default_solve_opts(lpx_solve_opts* o);
@@ -295,6 +306,29 @@ int  lpx_parse_text(const char* text, lpx_parsed* out);
 void lpx_parsed_free(lpx_parsed* p);
 /* ToString("0.###") as the reference renders tableau cells (Models/PrimalSimplex.cs:280) */
 int  lpx_format_number(double v, char* buf, int len);
+
+/* ---- consumers of SimplexResult.Tableau / Basis ------------------------------------
+ * CuttingPlane / CuttingPlaneRevised (Models/CuttingPlane.cs:13-139, Models/CuttingPlaneRevised.cs:14-78) are
+ * reached through lpx_solve with the menu names Form1.cs:249-261 uses: "Cutting Plane", "Revised Cutting Plane".
+ *
+ * SensitivityAnalysis (Models/SensitivityAnalysis.cs:11-297) over a problem and the final (T, basis) of a solve of
+ * it; VarNames are the reference's x1..xn, c1..cm.  Every call repeats the constructor's checks (:24-43) and
+ * returns the negative code with the reference's message in lpx_last_error.  Text is copied into buf (NUL
+ * terminated, truncated to len); the return value is the full length.  The reference indexes the tableau as if
+ * its objective row came first (:122,:237,:263,:279) -- kept. */
+int lpx_sensitivity_range_report(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                 const char* target, char* buf, int len);                  /* GetRangeReport :47-76 */
+int lpx_sensitivity_range(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                          const char* target, double* min, double* max);                   /* its numbers, :229-298 */
+/* ApplyChange :78-107.  The model belongs to the caller: *field = 0 -> Constraints[*index].B = value,
+ * 1 -> C[*index] = value is what the reference would have assigned. */
+int lpx_sensitivity_apply_change(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                 const char* target, double value, int* field, int* index, char* buf, int len);
+int lpx_sensitivity_shadow_prices(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                  char* buf, int len);                                     /* GetShadowPricesReport :109-128 */
+/* SolveUsingDuality :130-219: builds the dual model and runs "Dual Simplex" on it (opts->dual_flags as lpx_solve). */
+int lpx_sensitivity_solve_duality(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                  const lpx_solve_opts* o, lpx_result* out);
 
 #ifdef __cplusplus
 }

@@ -7,10 +7,12 @@ from . import _lib
 from ._lib import LpxError, default_opts
 from .tableau import DeviceTableau, primal_tableau, dual_tableau, multi_run
 from .revised import DeviceRevised, invert
-from .solver import (BranchAndBound, BranchAndBoundKnapsack, BranchAndBoundRevised, Constraint, DeviceKnapsack, DualSimplex, LPProblem,
+from .solver import (BranchAndBound, BranchAndBoundKnapsack, BranchAndBoundRevised, Constraint, CuttingPlane,
+                     CuttingPlaneRevised, DeviceKnapsack, DualSimplex, LPProblem, SensitivityAnalysis,
                      LPSolver, ParseFromText, PrimalSimplex, Rel, RevisedPrimalSimplex, Sense, SimplexResult,
                      SolverException)
 
 __all__ = ["_lib", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau", "multi_run", "DeviceRevised", "invert", "LPSolver", "LPProblem", "Constraint", "Sense", "Rel",
            "SimplexResult", "SolverException", "PrimalSimplex", "RevisedPrimalSimplex", "DualSimplex",
-           "BranchAndBound", "BranchAndBoundKnapsack", "BranchAndBoundRevised", "ParseFromText", "DeviceKnapsack"]
+           "BranchAndBound", "BranchAndBoundKnapsack", "BranchAndBoundRevised", "ParseFromText", "DeviceKnapsack",
+           "CuttingPlane", "CuttingPlaneRevised", "SensitivityAnalysis"]

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LPX_LIB_PATH") or os.path.join(_PKG, "liblpx.so")
 
 # status / error codes (include/lpx.h)
 OPTIMAL, UNBOUNDED, INFEASIBLE, ITER_LIMIT, RUNNING = 0, 1, 2, 3, 4
+CUT_INTEGER, CUT_INCOMPLETE, CUT_ERROR, CUT_NOT_OPTIMAL = 0, 10, 11, 12
 EINVAL, EDEVICE, ENOMEM = -1, -2, -3
 E_GE_PRESENT, E_NEG_RHS, E_REVISED_PRECOND, E_SINGULAR, E_KNAP_SHAPE, E_UNKNOWN_ALGO, E_PARSE = (
     -10, -11, -12, -13, -14, -15, -16)
@@ -70,7 +71,7 @@ class Result(C.Structure):
                 ("n", C.c_int), ("x", dp), ("R", C.c_int), ("C", C.c_int), ("T", dp), ("basis", ip),
                 ("n_pivots", C.c_int), ("trace", ip), ("report", C.c_char_p), ("summary", C.c_char_p),
                 ("lp_solves", C.c_int64), ("nodes", C.c_int64), ("n_log", C.c_int), ("node_log", ip),
-                ("node_z", dp), ("aux", C.c_double * 4), ("stats", Stats)]
+                ("node_z", dp), ("aux", C.c_double * 4), ("stats", Stats), ("n_cuts", C.c_int), ("cuts", dp)]
 
 
 class Parsed(C.Structure):
@@ -129,6 +130,13 @@ def lib() -> C.CDLL:
     L.lpx_revised_run.argtypes = [vp, C.POINTER(RunOpts), PIVOT_CB, vp, C.POINTER(Stats)]
     L.lpx_revised_result.argtypes = [vp, ip, ip, dp, dp]
     L.lpx_revised_binv.argtypes = [vp, dp]
+    L.lpx_revised_iteration_view.argtypes = [vp, dp, dp]
+    _sens = [C.POINTER(Problem), dp, C.c_int, C.c_int, ip]
+    L.lpx_sensitivity_range_report.argtypes = _sens + [C.c_char_p, C.c_char_p, C.c_int]
+    L.lpx_sensitivity_range.argtypes = _sens + [C.c_char_p, dp, dp]
+    L.lpx_sensitivity_apply_change.argtypes = _sens + [C.c_char_p, C.c_double, ip, ip, C.c_char_p, C.c_int]
+    L.lpx_sensitivity_shadow_prices.argtypes = _sens + [C.c_char_p, C.c_int]
+    L.lpx_sensitivity_solve_duality.argtypes = _sens + [C.POINTER(SolveOpts), C.POINTER(Result)]
     L.lpx_revised_refactor.argtypes = [vp]
     L.lpx_revised_set_refactor.argtypes = [vp, C.c_int]
     L.lpx_invert.argtypes = [dp, C.c_int, dp]

@@ -106,6 +106,63 @@ std::string AppendTableau(const std::string& title, const double* T, int R, int 
     return sb;
 }
 
+// MatrixToString, Models/RevisedPrimalSimplex.cs:248-261: 12-character right-aligned "0.###" cells.
+std::string MatrixToString(const double* M, int r, int c)
+{
+    std::string sb;
+    sb.reserve((size_t)r * ((size_t)c * 12 + 1));
+    for (int i = 0; i < r; ++i) {
+        for (int j = 0; j < c; ++j) sb += pad_left(FormatNumber(M[(size_t)i * c + j]), 12);
+        sb += "\n";
+    }
+    return sb;
+}
+
+// BuildIterationBlock, Models/RevisedPrimalSimplex.cs:191-246.  rN / d may be null (iteration 0); entering < 0
+// and a NaN theta stand for the reference's null arguments.  Nidx is the list AFTER the pivot while rN is
+// in the order priced BEFORE it -- the reference labels them that way (:219-220) and so does this.
+std::string BuildIterationBlock(int iter, const std::vector<int32_t>& Bidx, const std::vector<int32_t>& Nidx,
+                                const std::vector<std::string>& names, const double* Binv, int m,
+                                const std::vector<double>& xB, double z, const std::vector<double>* rN,
+                                int entering, const std::vector<double>* d, double bestTheta, double eps)
+{
+    auto join = [](const std::vector<std::string>& v) {
+        std::string o; for (size_t i = 0; i < v.size(); ++i) { if (i) o += ", "; o += v[i]; } return o; };
+    std::string sb = "=== Revised Simplex Iteration " + std::to_string(iter) + " ===\n";
+    std::vector<std::string> t;
+    for (int32_t k : Bidx) t.push_back(names[k]);
+    sb += "Basis: " + join(t) + "\n";
+    t.clear(); for (int32_t k : Nidx) t.push_back(names[k]);
+    sb += "Nonbasic: " + join(t) + "\n";
+    sb += "\nProduct-form: current B^{-1}\n";
+    sb += MatrixToString(Binv, m, m);
+    t.clear(); for (double v : xB) t.push_back(FormatNumber(v));
+    sb += "x_B = [" + join(t) + "]\n";
+    sb += "z = " + FormatNumber(z) + "\n";
+    if (rN) {
+        sb += "\nReduced costs (r_N = c_N - c_B^T B^{-1} N):\n";
+        for (size_t j = 0; j < rN->size(); ++j)
+            sb += "  r(" + std::to_string(Nidx[j]) + ":" + names[Nidx[j]] + ") = " + FormatNumber((*rN)[j]) + "\n";
+    }
+    if (entering >= 0) sb += "\nEntering variable: " + names[entering] + "\n";
+    if (d) {
+        sb += "Direction d = B^{-1} * a_entering:\n";
+        t.clear(); for (double v : *d) t.push_back(FormatNumber(v));
+        sb += "  d = [" + join(t) + "]\n";
+        sb += "\nRatio test (theta):\n";
+        for (size_t i = 0; i < d->size(); ++i) {
+            if ((*d)[i] > eps)
+                sb += "  row " + std::to_string(i + 1) + ": " + FormatNumber(xB[i]) + " / " + FormatNumber((*d)[i]) +
+                      " = " + FormatNumber(xB[i] / (*d)[i]) + "\n";
+            else
+                sb += "  row " + std::to_string(i + 1) + ": d_i <= 0 (skip)\n";
+        }
+        if (!std::isnan(bestTheta)) sb += "Chosen theta* = " + FormatNumber(bestTheta) + "\n";
+    }
+    sb += "\n";
+    return sb;
+}
+
 static std::string term(double v, int j)
 {
     return std::string(v >= 0 ? "+" : "-") + FormatNumber(std::fabs(v)) + "x" + std::to_string(j + 1);

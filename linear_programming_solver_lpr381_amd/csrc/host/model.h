@@ -8,6 +8,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/lpx.h"
@@ -51,6 +52,7 @@ struct SimplexResult {                  // Models/PrimalSimplex.cs:38-49
     int64_t LpSolves = 0, Nodes = 0;    // branch-and-bound counters
     std::vector<int32_t> NodeLog;       // B&B: (depth, outcome, branching var) per visited node
     std::vector<double> NodeZ;
+    std::vector<double> Cuts;           // cutting plane: (A[0..n), B) per cut, in the order added
 };
 
 // The reference throws System.Exception with fixed messages; `code` is the LPX_E_* of include/lpx.h.
@@ -140,6 +142,43 @@ private:
     EngineOptions opt;
 };
 
+class CuttingPlane : public ILPAlgorithm {              // Models/CuttingPlane.cs:9-164
+public:
+    explicit CuttingPlane(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+class CuttingPlaneRevised : public ILPAlgorithm {       // Models/CuttingPlaneRevised.cs:9-112
+public:
+    explicit CuttingPlaneRevised(const EngineOptions& o = {}) : opt(o) {}
+    SimplexResult Solve(const LPProblem& problem, UpdatePivot updatePivot = nullptr) override;
+private:
+    EngineOptions opt;
+};
+
+// Models/SensitivityAnalysis.cs:11-297.  `problem` is mutated by ApplyChange, as in the
+// reference; `result` must carry Tableau/Basis/VarNames (the constructor checks, :24-43).
+class SensitivityAnalysis {
+public:
+    SensitivityAnalysis(LPProblem* problem, const SimplexResult* result, const EngineOptions& o = {});
+    std::string GetRangeReport(const std::string& target) const;          // :47-76
+    std::string ApplyChange(const std::string& target, double value);     // :78-107
+    std::string GetShadowPricesReport() const;                            // :109-128
+    SimplexResult SolveUsingDuality() const;                              // :130-219
+    std::pair<double, double> Range(const std::string& target) const;     // GetRangeReport's numbers
+    void Locate(const std::string& target, int* field, int* index) const;  // entry ApplyChange assigns
+    std::pair<double, double> GetConstraintRange(int index) const;                    // :277-298
+    std::pair<double, double> GetBasicVariableObjectiveRange(int basicVarRow) const;  // :250-275
+    std::pair<double, double> GetNonBasicVariableRange(const std::string& varName) const;   // :229-248
+private:
+    bool basis_contains(int col) const;
+    int constraint_index(const std::string& target) const;
+    int var_column(const std::string& target) const;
+    LPProblem* problem; const SimplexResult* result; EngineOptions opt;
+};
+
 class LPSolver {                                        // Models/LPSolver.cs:6-77
 public:
     explicit LPSolver(const EngineOptions& o = {}) : opt(o) {}
@@ -157,10 +196,16 @@ LPProblem ParseFromText(const std::string& input);
 std::string FormatNumber(double v);                 // ToString("0.###")
 std::string FormatF(double v, int decimals);        // ToString("F3"/"F6", InvariantCulture)
 std::string FormatRound3(double v);                 // $"{Math.Round(v, 3):0.###}"
+std::string FormatShortest(double v);               // double.ToString(): shortest round-trippable digits
 double RoundHalfEven(double v, int decimals);       // Math.Round(v, decimals)
 std::string AppendTableau(const std::string& title, const double* T, int R, int C,
                           const std::vector<int32_t>& basis, const std::vector<std::string>& varNames, int iter);
 std::string AppendCanonicalForm(const LPProblem& model);
+std::string MatrixToString(const double* M, int r, int c);
+std::string BuildIterationBlock(int iter, const std::vector<int32_t>& Bidx, const std::vector<int32_t>& Nidx,
+                                const std::vector<std::string>& names, const double* Binv, int m,
+                                const std::vector<double>& xB, double z, const std::vector<double>* rN,
+                                int entering, const std::vector<double>* d, double bestTheta, double eps);
 
 // helpers shared by the solver mirrors (solvers.cpp)
 void BuildTableauPrimal(const LPProblem& expanded, std::vector<double>& T, int& R, int& C,

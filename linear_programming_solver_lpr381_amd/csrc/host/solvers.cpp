@@ -309,6 +309,44 @@ SimplexResult DualSimplex::Solve(const LPProblem& original, UpdatePivot updatePi
     return res;
 }
 
+// Per-iteration text of the revised path.  render: the reference's whole BuildIterationBlock (:191-246; m^2
+// formatted numbers per iteration, so one iteration per batch and a state download each); otherwise a
+// three-line event.  The ratio lines of the reference use the x_B AFTER the pivot (:131,:139) with the d of
+// before it -- reproduced as is.
+namespace {
+struct RevCtx {
+    UpdatePivot cb; const std::vector<std::string>* names; bool render; lpx_revised* h; int m, n; double eps;
+    std::vector<int32_t> NidxPrev;
+};
+
+void revised_block(RevCtx* c, int iter, int row, int col)
+{
+    const int m = c->m, n = c->n;
+    std::vector<int32_t> Bidx(m), Nidx(n); std::vector<double> xB(m), Binv((size_t)m * m); double z = 0;
+    if (lpx_revised_result(c->h, Bidx.data(), Nidx.data(), xB.data(), &z) || lpx_revised_binv(c->h, Binv.data())) return;
+    if (iter == 0) {
+        c->cb(BuildIterationBlock(0, Bidx, Nidx, *c->names, Binv.data(), m, xB, z, nullptr, -1, nullptr, NAN, c->eps), nullptr);
+    } else {
+        std::vector<double> rc(n + m), d(m), rN(n);
+        if (lpx_revised_iteration_view(c->h, rc.data(), d.data())) return;
+        for (int j = 0; j < n; ++j) rN[j] = rc[c->NidxPrev[j]];
+        Highlight hl; hl.R = m; hl.C = 4; hl.cells.assign((size_t)m * 4, 0);                   // :136-137
+        for (int j = 0; j < 4; ++j) hl.cells[(size_t)row * 4 + j] = 1;
+        c->cb(BuildIterationBlock(iter, Bidx, Nidx, *c->names, Binv.data(), m, xB, z, &rN, col, &d, xB[row], c->eps), &hl);
+    }
+    c->NidxPrev = Nidx;
+}
+
+void revised_event(void* user, int iter, int row, int col)
+{
+    RevCtx* c = static_cast<RevCtx*>(user);
+    if (!c->cb) return;
+    if (c->render) { revised_block(c, iter, row, col); return; }
+    c->cb("=== Revised Simplex Iteration " + std::to_string(iter) + " ===\nEntering variable: " +
+          (*c->names)[col] + "\nLeaving row: " + std::to_string(row + 1) + "\n\n", nullptr);
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------
 // RevisedPrimalSimplex.Solve, Models/RevisedPrimalSimplex.cs:17-145
 // ---------------------------------------------------------------------------------------------------
@@ -339,13 +377,10 @@ SimplexResult RevisedPrimalSimplex::Solve(const LPProblem& original, UpdatePivot
     SimplexResult res;
     lpx_run_opts o; lpx_default_opts(&o, 1);
     o.max_iter = opt.max_iter; o.batch = opt.batch;
-    struct RCtx { UpdatePivot cb; const std::vector<std::string>* names; } rctx{updatePivot, &names};
-    auto ev = [](void* user, int iter, int row, int col) {
-        RCtx* c = static_cast<RCtx*>(user);
-        if (c->cb) c->cb("=== Revised Simplex Iteration " + std::to_string(iter) + " ===\nEntering variable: " +
-                         (*c->names)[col] + "\nLeaving row: " + std::to_string(row + 1) + "\n\n", nullptr);
-    };
-    int st = lpx_revised_run(h, &o, updatePivot ? +ev : nullptr, &rctx, &res.Stats);
+    RevCtx rctx{updatePivot, &names, updatePivot && opt.render_iterations, h, m, n, o.eps, {}};
+    if (rctx.render) { o.batch = 1; revised_block(&rctx, 0, -1, -1); }                       // :62
+    auto ev = &revised_event;
+    int st = lpx_revised_run(h, &o, updatePivot ? ev : nullptr, &rctx, &res.Stats);
     if (st < 0) throw_lib(st);
     if (st == LPX_ITER_LIMIT) throw LpxException(LPX_ITER_LIMIT, "Iteration limit exceeded in Revised Primal Simplex.");   // :144
     std::vector<int32_t> Bidx(m), Nidx(n); std::vector<double> xB(m); double zint = 0;
@@ -375,6 +410,8 @@ SimplexResult RevisedPrimalSimplex::Solve(const LPProblem& original, UpdatePivot
     res.Basis = Bidx;
     return res;
 }
+
+std::string FormatShortest(double v) { return shortest(v); }
 
 // ---------------------------------------------------------------------------------------------------
 // LPSolver, Models/LPSolver.cs:16-76

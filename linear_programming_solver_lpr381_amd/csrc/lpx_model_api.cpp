@@ -35,19 +35,8 @@ LPProblem to_problem(const lpx_problem* p)
 
 }  // namespace
 
-extern "C" {
-
-void lpx_default_solve_opts(lpx_solve_opts* o)
+static EngineOptions to_engine(const lpx_solve_opts* o)
 {
-    std::memset(o, 0, sizeof(*o));
-    o->max_iter = 10000; o->concurrent_nodes = 1; o->world = 1;
-}
-
-int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts* o, lpx_result* out)
-{
-    if (!p || !algorithm || !out) { set_error("lpx_solve: null argument"); return LPX_EINVAL; }
-    std::memset(out, 0, sizeof(*out));
-    lpx_solve_opts d; if (!o) { lpx_default_solve_opts(&d); o = &d; }
     EngineOptions e;
     e.max_iter = o->max_iter > 0 ? o->max_iter : 10000;
     e.batch = o->batch; e.render_iterations = o->render_iterations != 0;
@@ -69,6 +58,11 @@ int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts*
         e.test_knap_relax = [fn, u](int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,
                                     double* weight, int32_t* frac, double* fracval) { return fn(u, count, off, fidx, fval, profit, weight, frac, fracval); };
     }
+    return e;
+}
+
+static UpdatePivot to_callback(const lpx_solve_opts* o)
+{
     UpdatePivot cb;
     if (o->text_cb) {
         auto fn = o->text_cb; void* u = o->text_user;
@@ -76,22 +70,80 @@ int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts*
             fn(u, text.c_str(), h ? h->cells.data() : nullptr, h ? h->R : 0, h ? h->C : 0);
         };
     }
+    return cb;
+}
+
+static void fill_result(lpx_result* out, const SimplexResult& r, int nvars)
+{
+    out->status = r.Status;
+    out->has_solution = r.HasSolution ? 1 : 0;
+    out->optimal_value = r.OptimalValue;
+    out->n = (int)r.Solution.size(); out->x = dup_vec(r.Solution);
+    out->R = r.R; out->C = r.C; out->T = dup_vec(r.Tableau);
+    out->basis = dup_vec(r.Basis);
+    out->n_pivots = (int)(r.Trace.size() / 2); out->trace = dup_vec(r.Trace);
+    out->report = dup_str(r.Report); out->summary = dup_str(r.Summary);
+    out->lp_solves = r.LpSolves; out->nodes = r.Nodes;
+    out->n_log = (int)(r.NodeLog.size() / 3); out->node_log = dup_vec(r.NodeLog); out->node_z = dup_vec(r.NodeZ);
+    for (size_t i = 0; i < 4 && i < r.NodeZ.size() && r.NodeLog.empty(); ++i) out->aux[i] = r.NodeZ[i];
+    out->stats = r.Stats;
+    out->n_cuts = nvars >= 0 ? (int)(r.Cuts.size() / (size_t)(nvars + 1)) : 0; out->cuts = dup_vec(r.Cuts);
+}
+
+// ---- SensitivityAnalysis over caller-owned arrays (include/lpx.h) -----------------------------------------
+namespace {
+struct SensCtx {
+    LPProblem q; SimplexResult r;
+    SensCtx(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis)
+    {
+        q = to_problem(p);
+        r.HasSolution = T != nullptr;
+        if (T && R > 0 && C > 0) r.Tableau.assign(T, T + (size_t)R * C);
+        r.R = R; r.C = C;
+        if (basis && R > 1) r.Basis.assign(basis, basis + (R - 1));
+        const int n = p->n, ns = C - 1 - n;                       // VarNames as BuildTableau names them, PrimalSimplex.cs:200-201
+        for (int j = 0; j < n; ++j) r.VarNames.push_back("x" + std::to_string(j + 1));
+        for (int j = 0; j < ns; ++j) r.VarNames.push_back("c" + std::to_string(j + 1));
+    }
+};
+int copy_out(const std::string& s, char* buf, int len)
+{
+    if (buf && len > 0) { std::strncpy(buf, s.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
+    return (int)s.size();
+}
+template <class F> int guarded(const char* what, F&& f)
+{
+    try { return f(); }
+    catch (const LpxException& ex) { set_error(ex.what()); return ex.code; }
+    catch (const std::exception& ex) { set_error(std::string(what) + ": " + ex.what()); return LPX_EINVAL; }
+}
+}  // namespace
+
+extern "C" {
+
+void lpx_default_solve_opts(lpx_solve_opts* o)
+{
+    std::memset(o, 0, sizeof(*o));
+    o->max_iter = 10000; o->concurrent_nodes = 1; o->world = 1;
+}
+
+int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts* o, lpx_result* out)
+{
+    if (!p || !algorithm || !out) { set_error("lpx_solve: null argument"); return LPX_EINVAL; }
+    std::memset(out, 0, sizeof(*out));
+    lpx_solve_opts d; if (!o) { lpx_default_solve_opts(&d); o = &d; }
     try {
+        EngineOptions e = to_engine(o);
+        UpdatePivot cb = to_callback(o);
         LPProblem q = to_problem(p);
-        LPSolver solver(e);
-        SimplexResult r = solver.Solve(q, algorithm, cb);
-        out->status = r.Status;
-        out->has_solution = r.HasSolution ? 1 : 0;
-        out->optimal_value = r.OptimalValue;
-        out->n = (int)r.Solution.size(); out->x = dup_vec(r.Solution);
-        out->R = r.R; out->C = r.C; out->T = dup_vec(r.Tableau);
-        out->basis = dup_vec(r.Basis);
-        out->n_pivots = (int)(r.Trace.size() / 2); out->trace = dup_vec(r.Trace);
-        out->report = dup_str(r.Report); out->summary = dup_str(r.Summary);
-        out->lp_solves = r.LpSolves; out->nodes = r.Nodes;
-        out->n_log = (int)(r.NodeLog.size() / 3); out->node_log = dup_vec(r.NodeLog); out->node_z = dup_vec(r.NodeZ);
-        for (size_t i = 0; i < 4 && i < r.NodeZ.size() && r.NodeLog.empty(); ++i) out->aux[i] = r.NodeZ[i];
-        out->stats = r.Stats;
+        SimplexResult r;
+        // Form1.btnSolve_Click (Form1.cs:249-261) builds the two cutting-plane solvers itself; LPSolver does not
+        // know them (Models/LPSolver.cs:18-43), so they are routed here and not in the LPSolver mirror.
+        const std::string key = LPSolver::NormalizeAlgorithmKey(algorithm);
+        if (key == "cutting plane") r = CuttingPlane(e).Solve(q, cb);
+        else if (key == "revised cutting plane" || key == "cutting plane revised") r = CuttingPlaneRevised(e).Solve(q, cb);
+        else r = LPSolver(e).Solve(q, algorithm, cb);
+        fill_result(out, r, p->n);
         return 0;
     } catch (const LpxException& ex) {
         set_error(ex.what());
@@ -102,11 +154,77 @@ int lpx_solve(const lpx_problem* p, const char* algorithm, const lpx_solve_opts*
     }
 }
 
+int lpx_sensitivity_range_report(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                 const char* target, char* buf, int len)
+{
+    if (!p || !target) { set_error("lpx_sensitivity_range_report: null argument"); return LPX_EINVAL; }
+    return guarded("lpx_sensitivity_range_report", [&]() -> int {
+        SensCtx c(p, T, R, C, basis);
+        SensitivityAnalysis sa(&c.q, &c.r);
+        return copy_out(sa.GetRangeReport(target), buf, len);
+    });
+}
+
+int lpx_sensitivity_range(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                          const char* target, double* mn, double* mx)
+{
+    if (!p || !target || !mn || !mx) { set_error("lpx_sensitivity_range: null argument"); return LPX_EINVAL; }
+    return guarded("lpx_sensitivity_range", [&]() -> int {
+        SensCtx c(p, T, R, C, basis);
+        SensitivityAnalysis sa(&c.q, &c.r);
+        std::pair<double, double> r = sa.Range(target);
+        *mn = r.first; *mx = r.second;
+        return 0;
+    });
+}
+
+int lpx_sensitivity_apply_change(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                 const char* target, double value, int* field, int* index, char* buf, int len)
+{
+    if (!p || !target) { set_error("lpx_sensitivity_apply_change: null argument"); return LPX_EINVAL; }
+    return guarded("lpx_sensitivity_apply_change", [&]() -> int {
+        SensCtx c(p, T, R, C, basis);
+        SensitivityAnalysis sa(&c.q, &c.r);
+        int f = -1, ix = -1;
+        sa.Locate(target, &f, &ix);
+        std::string msg = sa.ApplyChange(target, value);
+        if (field) *field = f;
+        if (index) *index = ix;
+        return copy_out(msg, buf, len);
+    });
+}
+
+int lpx_sensitivity_shadow_prices(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                  char* buf, int len)
+{
+    if (!p) { set_error("lpx_sensitivity_shadow_prices: null argument"); return LPX_EINVAL; }
+    return guarded("lpx_sensitivity_shadow_prices", [&]() -> int {
+        SensCtx c(p, T, R, C, basis);
+        SensitivityAnalysis sa(&c.q, &c.r);
+        return copy_out(sa.GetShadowPricesReport(), buf, len);
+    });
+}
+
+int lpx_sensitivity_solve_duality(const lpx_problem* p, const double* T, int R, int C, const int32_t* basis,
+                                  const lpx_solve_opts* o, lpx_result* out)
+{
+    if (!p || !out) { set_error("lpx_sensitivity_solve_duality: null argument"); return LPX_EINVAL; }
+    std::memset(out, 0, sizeof(*out));
+    lpx_solve_opts d; if (!o) { lpx_default_solve_opts(&d); o = &d; }
+    return guarded("lpx_sensitivity_solve_duality", [&]() -> int {
+        SensCtx c(p, T, R, C, basis);
+        SensitivityAnalysis sa(&c.q, &c.r, to_engine(o));
+        SimplexResult r = sa.SolveUsingDuality();
+        fill_result(out, r, -1);
+        return 0;
+    });
+}
+
 void lpx_result_free(lpx_result* r)
 {
     if (!r) return;
     std::free(r->x); std::free(r->T); std::free(r->basis); std::free(r->trace); std::free(r->report);
-    std::free(r->summary); std::free(r->node_log); std::free(r->node_z);
+    std::free(r->summary); std::free(r->node_log); std::free(r->node_z); std::free(r->cuts);
     std::memset(r, 0, sizeof(*r));
 }
 

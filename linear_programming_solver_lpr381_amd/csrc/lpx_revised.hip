@@ -125,7 +125,9 @@ __global__ __launch_bounds__(RV_NT) void rv_price_pick(RvParams P)
     }
     for (int s = t; s < P.m; s += RV_NT) {
         const int k = P.key[P.n + s];
-        if (k >= 0) { Cand c; c.v = 0.0 - pi[s]; c.key = k; c.col = P.n + s; if (c.v < -P.eps) best = cand_pick(best, c); }
+        const double rs = k >= 0 ? 0.0 - pi[s] : __builtin_inf();
+        P.rc[P.n + s] = rs;                             // kept for lpx_revised_iteration_view (report text)
+        if (k >= 0) { Cand c; c.v = rs; c.key = k; c.col = P.n + s; if (c.v < -P.eps) best = cand_pick(best, c); }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -440,7 +442,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
              hipFree(Atmp); lpx_revised_destroy(r); return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE; } } while (0)
     RALLOC(r->AT, atb); RALLOC(r->c, sizeof(double) * n); RALLOC(r->W, wb);
     RALLOC(r->prow, sizeof(double) * r->ldw); RALLOC(r->fac, sizeof(double) * (m + 1));
-    RALLOC(r->rhsbuf, sizeof(double) * (m + 1)); RALLOC(r->rc, sizeof(double) * n);
+    RALLOC(r->rhsbuf, sizeof(double) * (m + 1)); RALLOC(r->rc, sizeof(double) * (n + m));
     RALLOC(r->aq, sizeof(double) * r->ldat); RALLOC(r->ws, sizeof(double) * (m + 1));
     RALLOC(r->Bidx, sizeof(int32_t) * m); RALLOC(r->key, sizeof(int32_t) * (n + m));
     RALLOC(r->trace, sizeof(int32_t) * 2 * r->trace_cap); RALLOC(r->st, sizeof(DevState));
@@ -607,6 +609,15 @@ int lpx_revised_binv(lpx_revised* r, double* Binv)
     if (!r || !Binv) return LPX_EINVAL;
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
     LPX_HIP_TRY(hipMemcpy2D(Binv, sizeof(double) * r->m, r->W, sizeof(double) * r->ldw, sizeof(double) * r->m, r->m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lpx_revised_iteration_view(lpx_revised* r, double* rc, double* d)
+{
+    if (!r) return LPX_EINVAL;
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    if (rc) LPX_HIP_TRY(hipMemcpy(rc, r->rc, sizeof(double) * (r->n + r->m), hipMemcpyDeviceToHost));
+    if (d) LPX_HIP_TRY(hipMemcpy(d, r->fac, sizeof(double) * r->m, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -68,6 +68,7 @@ class SimplexResult:        # Models/PrimalSimplex.cs:38-49 (+ engine extras aft
     Aux: Optional[list] = None
     Stats: Optional[dict] = None
     Extra: Optional[np.ndarray] = None      # revised / knapsack: numbers the reference only prints
+    Cuts: Optional[np.ndarray] = None       # cutting plane: rows (A[0..n), B) in the order added
 
 
 class SolverException(Exception):
@@ -102,6 +103,64 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
+def _solve_opts(engine: dict):
+    """lpx_solve_opts from keyword engine options; returns (opts, objects to keep alive)."""
+    L = lib()
+    o = _lib.SolveOpts()
+    L.lpx_default_solve_opts(C.byref(o))
+    keep = []
+    for k, v in engine.items():
+        if k == "allreduce_max":
+            fn = v
+
+            def _ar(_u, vals, count, fn=fn):
+                a = np.ctypeslib.as_array(vals, shape=(count,))
+                a[:] = fn(a.copy())
+            cb = _lib.ALLREDUCE_CB(_ar)
+            keep.append(cb)
+            o.allreduce_max = cb
+        elif k in ("test_node_lp", "test_knap_relax"):
+            cb = (_lib.TEST_NODE_LP if k == "test_node_lp" else _lib.TEST_KNAP_RELAX)(v)
+            keep.append(cb)
+            setattr(o, k, cb)
+        elif hasattr(o, k):
+            setattr(o, k, v)
+        else:
+            raise TypeError(f"unknown engine option {k!r}")
+    return o, keep
+
+
+def _take_result(r, n: int) -> "SimplexResult":
+    """Copies an lpx_result into a SimplexResult and frees it. n = NumVars of the solved model."""
+    try:
+        has = bool(r.has_solution)
+        T = _arr(r.T, r.R * r.C, np.float64).reshape(r.R, r.C) if r.R > 0 else None
+        names = None
+        if has and T is not None:
+            ns = T.shape[1] - 1
+            names = [f"x{j + 1}" for j in range(n)] + [f"c{j + 1}" for j in range(ns - n)]
+        log = _arr(r.node_log, 3 * r.n_log, np.int32).reshape(-1, 3)
+        res = SimplexResult(
+            Report=(r.report or b"").decode(errors="replace"), Summary=(r.summary or b"").decode(errors="replace"),
+            OptimalValue=r.optimal_value,
+            Solution=_arr(r.x, r.n, np.float64) if has else None,
+            Tableau=T if has else None,
+            Basis=_arr(r.basis, max(r.R - 1, 0), np.int32) if has else None,
+            VarNames=names, Status=r.status,
+            Trace=_arr(r.trace, 2 * r.n_pivots, np.int32).reshape(-1, 2),
+            LpSolves=r.lp_solves, Nodes=r.nodes, NodeLog=log, NodeZ=_arr(r.node_z, r.n_log, np.float64),
+            Aux=list(r.aux), Stats=r.stats.as_dict(),
+            Extra=None if has else (T.reshape(-1) if T is not None and T.size else _arr(r.x, r.n, np.float64)),
+            Cuts=_arr(r.cuts, r.n_cuts * (n + 1), np.float64).reshape(-1, n + 1) if r.n_cuts > 0 else None)
+        if not has and r.n > 0:
+            res.Extra = _arr(r.x, r.n, np.float64)
+        elif not has and T is not None:
+            res.Extra = T.reshape(-1)
+    finally:
+        lib().lpx_result_free(C.byref(r))
+    return res
+
+
 class LPSolver:             # Models/LPSolver.cs:6-77
     def __init__(self, **engine):
         self.engine = engine
@@ -110,27 +169,7 @@ class LPSolver:             # Models/LPSolver.cs:6-77
     def Solve(self, problem: LPProblem, algorithm: str,
               updatePivot: Optional[Callable[[str, Optional[np.ndarray]], None]] = None) -> SimplexResult:
         L = lib()
-        o = _lib.SolveOpts()
-        L.lpx_default_solve_opts(C.byref(o))
-        keep = []
-        for k, v in self.engine.items():
-            if k == "allreduce_max":
-                fn = v
-
-                def _ar(_u, vals, count, fn=fn):
-                    a = np.ctypeslib.as_array(vals, shape=(count,))
-                    a[:] = fn(a.copy())
-                cb = _lib.ALLREDUCE_CB(_ar)
-                keep.append(cb)
-                o.allreduce_max = cb
-            elif k in ("test_node_lp", "test_knap_relax"):
-                cb = (_lib.TEST_NODE_LP if k == "test_node_lp" else _lib.TEST_KNAP_RELAX)(v)
-                keep.append(cb)
-                setattr(o, k, cb)
-            elif hasattr(o, k):
-                setattr(o, k, v)
-            else:
-                raise TypeError(f"unknown engine option {k!r}")
+        o, keep = _solve_opts(self.engine)
         if updatePivot is not None:
             def _txt(_u, text, hl, R, Cc):
                 mask = None
@@ -145,32 +184,7 @@ class LPSolver:             # Models/LPSolver.cs:6-77
         rc = L.lpx_solve(C.byref(ps), algorithm.encode() if algorithm is not None else b"", C.byref(o), C.byref(r))
         if rc != 0:
             raise SolverException(rc, _lib.last_error())
-        try:
-            has = bool(r.has_solution)
-            T = _arr(r.T, r.R * r.C, np.float64).reshape(r.R, r.C) if r.R > 0 else None
-            n = problem.NumVars
-            names = None
-            if has and T is not None:
-                ns = T.shape[1] - 1
-                names = [f"x{j + 1}" for j in range(n)] + [f"c{j + 1}" for j in range(ns - n)]
-            log = _arr(r.node_log, 3 * r.n_log, np.int32).reshape(-1, 3)
-            res = SimplexResult(
-                Report=(r.report or b"").decode(errors="replace"), Summary=(r.summary or b"").decode(errors="replace"),
-                OptimalValue=r.optimal_value,
-                Solution=_arr(r.x, r.n, np.float64) if has else None,
-                Tableau=T if has else None,
-                Basis=_arr(r.basis, max(r.R - 1, 0), np.int32) if has else None,
-                VarNames=names, Status=r.status,
-                Trace=_arr(r.trace, 2 * r.n_pivots, np.int32).reshape(-1, 2),
-                LpSolves=r.lp_solves, Nodes=r.nodes, NodeLog=log, NodeZ=_arr(r.node_z, r.n_log, np.float64),
-                Aux=list(r.aux), Stats=r.stats.as_dict(),
-                Extra=None if has else (T.reshape(-1) if T is not None and T.size else _arr(r.x, r.n, np.float64)))
-            if not has and r.n > 0:
-                res.Extra = _arr(r.x, r.n, np.float64)
-            elif not has and T is not None:
-                res.Extra = T.reshape(-1)
-        finally:
-            L.lpx_result_free(C.byref(r))
+        res = _take_result(r, problem.NumVars)
         self.FinalTableau = res.Tableau
         return res
 
@@ -207,6 +221,84 @@ class BranchAndBoundRevised(_Algo):     # Models/BranchAndBoundRevised.cs:17
 
 class BranchAndBoundKnapsack(_Algo):    # Models/BranchAndBoundKnapsack.cs:12
     NAME = "Branch and Bound Knapsack"
+
+
+class CuttingPlane(_Algo):              # Models/CuttingPlane.cs:9 (built by Form1.cs:251, not by LPSolver)
+    NAME = "Cutting Plane"
+
+
+class CuttingPlaneRevised(_Algo):       # Models/CuttingPlaneRevised.cs:9 (Form1.cs:258)
+    NAME = "Revised Cutting Plane"
+
+
+class SensitivityAnalysis:
+    """Models/SensitivityAnalysis.cs:11-297 over an LPProblem and the SimplexResult of solving it.
+    The constructor checks of :24-43 are repeated by every call (they run in the library)."""
+
+    def __init__(self, problem: LPProblem, result: SimplexResult, **engine):
+        if problem is None:
+            raise SolverException(_lib.EINVAL, "Value cannot be null. (Parameter 'problem')")
+        if result is None:
+            raise SolverException(_lib.EINVAL, "Value cannot be null. (Parameter 'result')")
+        self.problem, self.result, self.engine = problem, result, engine
+        self._call(lambda a: lib().lpx_sensitivity_shadow_prices(*a, None, 0))     # :24-43
+
+    def _args(self):
+        ps, hold = _problem_struct(self.problem)
+        T = self.result.Tableau
+        self._hold = hold
+        if T is None:
+            return [C.byref(ps), None, 0, 0, None], ps
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        basis = np.ascontiguousarray(self.result.Basis if self.result.Basis is not None else [], dtype=np.int32)
+        if len(basis) != T.shape[0] - 1:        # Basis length check of :40-41 needs the true length
+            raise SolverException(_lib.EINVAL, f"Basis length invalid. Expected {T.shape[0] - 1}, got {len(basis)}.")
+        self._hold = (hold, T, basis)
+        return [C.byref(ps), T.ctypes.data_as(_lib.dp), T.shape[0], T.shape[1], basis.ctypes.data_as(_lib.ip)], ps
+
+    def _call(self, fn):
+        a, _ps = self._args()
+        rc = fn(a)
+        if rc < 0:
+            raise SolverException(rc, _lib.last_error())
+        return rc
+
+    def _text(self, fn):
+        n = self._call(lambda a: fn(a, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        self._call(lambda a: fn(a, buf, n + 1))
+        return buf.value.decode()
+
+    def GetRangeReport(self, target: str) -> str:                       # :47-76
+        t = target.encode()
+        return self._text(lambda a, b, n: lib().lpx_sensitivity_range_report(*a, t, b, n))
+
+    def GetRange(self, target: str):
+        """The (min, max) GetRangeReport prints."""
+        mn, mx = C.c_double(), C.c_double()
+        self._call(lambda a: lib().lpx_sensitivity_range(*a, target.encode(), C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def ApplyChange(self, target: str, value: float) -> str:            # :78-107 (mutates self.problem)
+        t = target.encode()
+        f, ix = C.c_int(-1), C.c_int(-1)
+        msg = self._text(lambda a, b, n: lib().lpx_sensitivity_apply_change(*a, t, float(value), C.byref(f), C.byref(ix), b, n))
+        if f.value == 0:
+            self.problem.Constraints[ix.value].B = float(value)
+        elif f.value == 1:
+            c = list(self.problem.C)
+            c[ix.value] = float(value)
+            self.problem.C = c
+        return msg
+
+    def GetShadowPricesReport(self) -> str:                             # :109-128
+        return self._text(lambda a, b, n: lib().lpx_sensitivity_shadow_prices(*a, b, n))
+
+    def SolveUsingDuality(self) -> SimplexResult:                       # :130-219
+        o, keep = _solve_opts(self.engine)
+        r = _lib.Result()
+        self._call(lambda a: lib().lpx_sensitivity_solve_duality(*a, C.byref(o), C.byref(r)))
+        return _take_result(r, len(self.problem.Constraints))
 
 
 def ParseFromText(text: str) -> LPProblem:

@@ -84,6 +84,10 @@ void orc_pivot(double* T, int R, int C, int r, int q);                          
  * Returns ORC_OPTIMAL / ORC_UNBOUNDED / ORC_ITER_LIMIT. */
 int orc_primal_tableau(double* T, int R, int C, int32_t* basis, double eps, int max_iter,
                        int32_t* trace, int* n_pivots);
+/* Same loop with the row updates of Pivot spread over `threads` OpenMP threads (0 = all cores):
+ * the multi-core courtesy CPU baseline of bench.py; bit-identical results (primal_mt.c). */
+int orc_primal_tableau_mt(double* T, int R, int C, int32_t* basis, double eps, int max_iter,
+                          int32_t* trace, int* n_pivots, int threads);
 
 /* Dual loop on a prepared tableau (Models/DualSimplex.cs:24 + :36-113).
  * fdf_guard = 100 in the reference (:202).  cleanup!=0 adds the repaired-mode primal clean-up
@@ -166,6 +170,30 @@ enum {
 };
 void orc_bnb_result_free(orc_bnb_result* r);
 int orc_bnb_solve(const orc_problem* p, int mode, int max_iter, int64_t max_nodes, orc_bnb_result* out);
+/* ---- consumers of SimplexResult.Tableau / Basis, consumers.c --------------------- */
+enum {
+    ORC_CUT_INTEGER = 0,     /* "Status: OPTIMAL INTEGER", CuttingPlane.cs:91-104 / CuttingPlaneRevised.cs:49-57 */
+    ORC_CUT_INCOMPLETE = 1,  /* iteration limit 50, CuttingPlane.cs:132-137 / CuttingPlaneRevised.cs:70-77 */
+    ORC_CUT_ERROR = 2,       /* solver exception, CuttingPlane.cs:42-50 (CuttingPlaneRevised lets it propagate) */
+    ORC_CUT_NONBASIC = 3,    /* "Variable x.. is not basic", CuttingPlane.cs:116-124 */
+    ORC_CUT_NOT_OPTIMAL = 4  /* CuttingPlaneRevised.cs:27-35 */
+};
+typedef struct {
+    int status, error;
+    int n, n_cuts;
+    double* cut_A;           /* [n_cuts*n] cuts in the order they were added */
+    double* cut_b;           /* [n_cuts] */
+    double* x; double z;     /* last LP solution / objective the loop looked at */
+    int64_t lp_solves, total_pivots;
+} orc_cut_result;
+void orc_cut_result_free(orc_cut_result* r);
+int orc_cutting_plane(const orc_problem* p, int max_iter, orc_cut_result* out);          /* Models/CuttingPlane.cs:13-139 */
+int orc_cutting_plane_revised(const orc_problem* p, int max_iter, orc_cut_result* out);  /* Models/CuttingPlaneRevised.cs:14-78 */
+/* SensitivityAnalysis numbers, Models/SensitivityAnalysis.cs:229-298 and :109-128 (see consumers.c) */
+int orc_sens_range(const orc_problem* p, const double* T, int R, int C, const int32_t* basis,
+                   int kind, int index, double* pmin, double* pmax, int* which);
+void orc_sens_shadow_prices(const orc_problem* p, const double* T, int R, int C, double* shadow);
+
 /* BranchAndBoundRevised.Solve, Models/BranchAndBoundRevised.cs:27-98: same result record;
  * node x*, z* quantised to 3 decimals by the reference's Summary-text round trip. */
 int orc_bnbr_solve(const orc_problem* p, int mode, int max_iter, int64_t max_nodes, orc_bnb_result* out);

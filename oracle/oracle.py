@@ -65,6 +65,11 @@ class _KnapResult(C.Structure):
                 ("relaxations", C.c_int64), ("max_heap", C.c_int64)]
 
 
+class _CutResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("error", C.c_int), ("n", C.c_int), ("n_cuts", C.c_int), ("cut_A", _dp),
+                ("cut_b", _dp), ("x", _dp), ("z", C.c_double), ("lp_solves", C.c_int64), ("total_pivots", C.c_int64)]
+
+
 class _Parsed(C.Structure):
     _fields_ = [("sense", C.c_int), ("n", C.c_int), ("m", C.c_int), ("c", _dp), ("A", _dp),
                 ("rel", _ip), ("b", _dp), ("ragged", C.c_int)]
@@ -84,6 +89,8 @@ def lib():
         L.orc_pivot.restype = None
         L.orc_primal_tableau.argtypes = [_dp, C.c_int, C.c_int, _ip, C.c_double, C.c_int, _ip,
                                          C.POINTER(C.c_int)]
+        L.orc_primal_tableau_mt.argtypes = [_dp, C.c_int, C.c_int, _ip, C.c_double, C.c_int, _ip,
+                                            C.POINTER(C.c_int), C.c_int]
         L.orc_dual_tableau.argtypes = [_dp, C.c_int, C.c_int, _ip, C.c_double, C.c_double, C.c_int,
                                        C.c_int, C.c_int, _ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_forced_pivots.argtypes = [_dp, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_double, _ip]
@@ -107,6 +114,13 @@ def lib():
         L.orc_knapsack_order.restype = None
         L.orc_knapsack_relax.argtypes = [_dp, _dp, C.c_int, C.c_double, _ip, _ip, _dp, _dp, _dp, _ip]
         L.orc_knapsack_relax.restype = None
+        L.orc_cutting_plane.argtypes = [C.POINTER(_Problem), C.c_int, C.POINTER(_CutResult)]
+        L.orc_cutting_plane_revised.argtypes = [C.POINTER(_Problem), C.c_int, C.POINTER(_CutResult)]
+        L.orc_cut_result_free.argtypes = [C.POINTER(_CutResult)]
+        L.orc_cut_result_free.restype = None
+        L.orc_sens_range.argtypes = [C.POINTER(_Problem), _dp, C.c_int, C.c_int, _ip, C.c_int, C.c_int, _dp, _dp, _ip]
+        L.orc_sens_shadow_prices.argtypes = [C.POINTER(_Problem), _dp, C.c_int, C.c_int, _dp]
+        L.orc_sens_shadow_prices.restype = None
         L.orc_parse_text.argtypes = [C.c_char_p, C.POINTER(_Parsed), C.c_char_p, C.c_int]
         L.orc_parsed_free.argtypes = [C.POINTER(_Parsed)]
         L.orc_parsed_free.restype = None
@@ -209,12 +223,17 @@ def pivot(T, r, q):
     lib().orc_pivot(_d(T), T.shape[0], T.shape[1], r, q)
 
 
-def primal_tableau(T, basis, eps=1e-9, max_iter=10000):
-    """Runs the primal loop in place. Returns (status, trace[k,2])."""
+def primal_tableau(T, basis, eps=1e-9, max_iter=10000, threads=None):
+    """Runs the primal loop in place. Returns (status, trace[k,2]).  threads=None: the scalar
+    single-thread loop; threads=k (0 = all cores): OpenMP over the rows of Pivot, same bits."""
     assert T.flags.c_contiguous and T.dtype == np.float64 and basis.dtype == np.int32
     trace = np.zeros(2 * max(max_iter, 1), np.int32)
     n = C.c_int(0)
-    st = lib().orc_primal_tableau(_d(T), T.shape[0], T.shape[1], _i(basis), eps, max_iter, _i(trace), C.byref(n))
+    if threads is None:
+        st = lib().orc_primal_tableau(_d(T), T.shape[0], T.shape[1], _i(basis), eps, max_iter, _i(trace), C.byref(n))
+    else:
+        st = lib().orc_primal_tableau_mt(_d(T), T.shape[0], T.shape[1], _i(basis), eps, max_iter, _i(trace),
+                                         C.byref(n), int(threads))
     return st, trace[: 2 * n.value].reshape(-1, 2).copy()
 
 
@@ -355,3 +374,49 @@ def parse_text(text: str):
     ragged = bool(r.ragged)
     lib().orc_parsed_free(C.byref(r))
     return p, ragged
+
+
+# ---- consumers of SimplexResult.Tableau / Basis (consumers.c) -----------------------------------------
+CUT_INTEGER, CUT_INCOMPLETE, CUT_ERROR, CUT_NONBASIC, CUT_NOT_OPTIMAL = 0, 1, 2, 3, 4
+
+
+@dataclass
+class CutResult:
+    status: int
+    error: int
+    cuts: np.ndarray        # [n_cuts, n+1] = (A, B) in the order added
+    x: np.ndarray
+    z: float
+    lp_solves: int
+    total_pivots: int
+
+
+def cutting_plane(p: Problem, revised: bool = False, max_iter: int = 10000) -> CutResult:
+    """CuttingPlane.Solve (Models/CuttingPlane.cs:13-139) / CuttingPlaneRevised.Solve (:14-78)."""
+    r = _CutResult()
+    cp = p._c()
+    (lib().orc_cutting_plane_revised if revised else lib().orc_cutting_plane)(C.byref(cp), max_iter, C.byref(r))
+    A = _cp(r.cut_A, r.n_cuts * r.n, np.float64).reshape(r.n_cuts, r.n)
+    b = _cp(r.cut_b, r.n_cuts, np.float64).reshape(r.n_cuts, 1)
+    out = CutResult(r.status, r.error, np.hstack([A, b]), _cp(r.x, r.n, np.float64), r.z, r.lp_solves, r.total_pivots)
+    lib().orc_cut_result_free(C.byref(r))
+    return out
+
+
+def sens_range(p: Problem, T, basis, kind: int, index: int):
+    """SensitivityAnalysis range numbers: kind 0 = constraint `index`, 1 = variable column `index`.
+    Returns (rc, min, max, which) with which 0 constraint / 1 basic / 2 non-basic."""
+    T = np.ascontiguousarray(T, np.float64)
+    basis = np.ascontiguousarray(basis, np.int32)
+    mn, mx, w = np.zeros(1), np.zeros(1), np.zeros(1, np.int32)
+    cp = p._c()
+    rc = lib().orc_sens_range(C.byref(cp), _d(T), T.shape[0], T.shape[1], _i(basis), kind, index, _d(mn), _d(mx), _i(w))
+    return rc, float(mn[0]), float(mx[0]), int(w[0])
+
+
+def sens_shadow_prices(p: Problem, T):
+    T = np.ascontiguousarray(T, np.float64)
+    out = np.zeros(len(p.b))
+    cp = p._c()
+    lib().orc_sens_shadow_prices(C.byref(cp), _d(T), T.shape[0], T.shape[1], _d(out))
+    return out

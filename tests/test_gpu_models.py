@@ -49,6 +49,34 @@ def test_render_iterations_matches_reference_format(gpu):
     assert h1.shape == (4, 6) and h1[1].all() and h1[:, 1].all() and h1.sum() == 6 + 4 - 1
 
 
+def test_render_iterations_revised_matches_reference_block(gpu):
+    """BuildIterationBlock / MatrixToString (Models/RevisedPrimalSimplex.cs:191-261) on KAT-1, derived by
+    hand from the cited lines -- including the reference's quirks: r_N is labelled with the Nidx of AFTER
+    the pivot (:219-220) and the ratio lines divide the x_B of after it (:131,:139,:236)."""
+    p = gpu.ParseFromText(KATS["kat1_primal"]["text"])
+    texts = []
+    gpu.LPSolver(render_iterations=1).Solve(p, "Revised Primal Simplex", lambda t, h: texts.append((t, h)))
+    assert len(texts) == 3
+    cell = lambda *v: "".join(str(x).rjust(12) for x in v) + "\n"
+    assert texts[0][1] is None and texts[0][0] == (
+        "=== Revised Simplex Iteration 0 ===\nBasis: c1, c2, c3\nNonbasic: x1, x2\n\n"
+        "Product-form: current B^{-1}\n" + cell(1, 0, 0) + cell(0, 1, 0) + cell(0, 0, 1) +
+        "x_B = [4, 12, 18]\nz = 0\n\n")
+    t1, h1 = texts[1]
+    assert t1 == (
+        "=== Revised Simplex Iteration 1 ===\nBasis: c1, x2, c3\nNonbasic: x1, c2\n\n"
+        "Product-form: current B^{-1}\n" + cell(1, 0, 0) + cell(0, "0.5", 0) + cell(0, -1, 1) +
+        "x_B = [4, 6, 6]\nz = -30\n\n"
+        "Reduced costs (r_N = c_N - c_B^T B^{-1} N):\n  r(0:x1) = -3\n  r(3:c2) = -5\n\n"
+        "Entering variable: x2\nDirection d = B^{-1} * a_entering:\n  d = [0, 2, 2]\n\n"
+        "Ratio test (theta):\n  row 1: d_i <= 0 (skip)\n  row 2: 6 / 2 = 3\n  row 3: 6 / 2 = 3\n"
+        "Chosen theta* = 6\n\n")
+    assert h1.shape == (3, 4) and h1[1].all() and h1.sum() == 4
+    t2, _ = texts[2]
+    assert "Basis: c1, x2, x1\nNonbasic: c2, c3\n" in t2 and "x_B = [2, 6, 2]\nz = -36\n" in t2
+    assert "  r(3:c2) = -3\n  r(4:c3) = 2.5\n" in t2 and "Chosen theta* = 2\n" in t2
+
+
 def test_kat3_min_sign(gpu):
     k = KATS["kat3_min_sign"]
     r = gpu.PrimalSimplex().Solve(gpu.ParseFromText(k["text"]))

@@ -261,3 +261,69 @@ def test_kat9_bnb_revised(oracle, mode, key):
     e = k[key]
     assert r.best_z == e["best_z"] and r.best_x.tolist() == e["best_x"] and r.lp_solves == e["lp_solves"]
     assert r.log.tolist() == e["log"] and r.log_z.tolist() == e["log_z"]
+
+
+def test_multicore_baseline_variant_is_bit_identical(oracle):
+    """oracle/primal_mt.c (bench.py's all-cores courtesy baseline) == the scalar loop, bit for bit."""
+    from linear_programming_solver_lpr381_amd import synth
+    c, A, b = synth.dense_lp(96, 160, seed=5)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    T1, b1, T2, b2 = T.copy(), basis.copy(), T.copy(), basis.copy()
+    s1, tr1 = oracle.primal_tableau(T1, b1)
+    s2, tr2 = oracle.primal_tableau(T2, b2, threads=3)
+    assert s1 == s2 == 0 and len(tr1) > 20
+    assert np.array_equal(tr1, tr2) and np.array_equal(T1, T2) and np.array_equal(b1, b2)
+
+
+# ---- consumers of SimplexResult.Tableau / Basis (oracle/consumers.c), hand-derived -------------------------
+def test_kat10_cutting_plane_reads_the_row_below(oracle):
+    """Max x1, 2x1 <= 3.  LP: x1 = 1.5 basic in row 0, so Models/CuttingPlane.cs:109 reads row 0+1 -- the
+    OBJECTIVE row [0, 0.5 | 1.5] (BuildTableau puts it last): f0 = 0.5, f_1 = frac(0) = 0 -> the empty cut
+    `0 <= 0.5`.  Nothing changes, so all 50 iterations add that cut and the status is INCOMPLETE (:132-137)."""
+    p = oracle.Problem(oracle.MAX, [1.0], [[2.0]], [oracle.LE], [3.0])
+    r = oracle.cutting_plane(p)
+    assert r.status == oracle.CUT_INCOMPLETE and r.lp_solves == 50
+    assert r.cuts.tolist() == [[0.0, 0.5]] * 50 and r.x.tolist() == [1.5] and r.z == 1.5
+
+
+def test_kat11_cutting_plane_integral_at_once(oracle):
+    p = oracle.Problem(oracle.MAX, [1.0, 1.0], [[1, 0], [0, 1.0]], [oracle.LE, oracle.LE], [2.0, 3.0])
+    r = oracle.cutting_plane(p)
+    assert r.status == oracle.CUT_INTEGER and len(r.cuts) == 0 and r.x.tolist() == [2.0, 3.0] and r.z == 5.0
+
+
+def test_kat12_cutting_plane_revised(oracle):
+    """Same LP through CuttingPlaneRevised: x1 = 1.5 -> cut x1 <= floor(1.5 + 1e-12) = 1 (:59-66) -> x1 = 1."""
+    p = oracle.Problem(oracle.MAX, [1.0], [[2.0]], [oracle.LE], [3.0])
+    r = oracle.cutting_plane(p, revised=True)
+    assert r.status == oracle.CUT_INTEGER and r.cuts.tolist() == [[1.0, 1.0]] and r.x.tolist() == [1.0] and r.lp_solves == 2
+
+
+def test_kat13_sensitivity_on_kat1(oracle):
+    """Final tableau of KAT-1 (basis [c1, x2, x1]):
+         row0 [0 0 1  1/3 -1/3 |  2]   row1 [0 1 0 1/2 0 | 6]   row2 [1 0 0 -1/3 1/3 | 2]   obj [0 0 0 3/2 1 | 36]
+    SensitivityAnalysis treats row 0 as the objective row and row k+1 as constraint/basic row k:
+      x1 (basic in row 2 -> reads row 3): j=3: a=1.5, rc=T[0,3]=1/3 -> max 3-2/9; j=4: a=1, rc=-1/3 -> max 3+1/3
+      x2 (basic in row 1 -> reads row 2): j=3: a=-1/3, rc=1/3 -> min 5+1=6; j=4: a=1/3, rc=-1/3 -> max 5+1=6
+      c1/c2: problem.C[col] with col >= NumVars -> IndexOutOfRange;  constraints: both x columns basic -> (-inf, inf)
+      shadow prices: -T[0, 2+i] = -1, -1/3, +1/3."""
+    p = oracle.Problem(oracle.MAX, [3.0, 5.0], [[1, 0], [0, 2], [3, 2]], [0, 0, 0], [4, 12, 18.0])
+    res = oracle.primal_solve(p)
+    rng = lambda k, i: oracle.sens_range(p, res.T, res.basis, k, i)
+    assert rng(1, 0) == (0, -np.inf, 3.0 + (-(1.0 / 3.0) / 1.5), 1)
+    assert rng(1, 1) == (0, 6.0, 6.0, 1)
+    assert rng(1, 2)[0] < 0 and rng(1, 3)[0] < 0
+    assert rng(0, 0) == (0, -np.inf, np.inf, 0) and rng(0, 2) == (0, -np.inf, np.inf, 0)
+    assert oracle.sens_shadow_prices(p, res.T).tolist() == [-1.0, -(1.0 / 3.0), 1.0 / 3.0]
+
+
+def test_kat14_sensitivity_nonbasic(oracle):
+    """Max 3x1 + x2, x1 + x2 <= 4: final row0 [1 1 1 | 4], obj [0 2 3 | 12], basis [x1].
+       x2 non-basic: rc = T[0,1] = 1 > 0 -> max 1+1; Constraint 1 reads row 1 (obj): B=12, a=T[1,1]=2 -> max 12-6;
+       x1 basic row 0 reads row 1: j=1: a=2, rc=1 -> 3-0.5; j=2: a=3, rc=1 -> 3-1/3 -> max 2.5."""
+    p = oracle.Problem(oracle.MAX, [3.0, 1.0], [[1.0, 1.0]], [0], [4.0])
+    res = oracle.primal_solve(p)
+    assert oracle.sens_range(p, res.T, res.basis, 1, 1) == (0, -np.inf, 2.0, 2)
+    assert oracle.sens_range(p, res.T, res.basis, 0, 0) == (0, -np.inf, 6.0, 0)
+    assert oracle.sens_range(p, res.T, res.basis, 1, 0) == (0, -np.inf, 2.5, 1)
+    assert oracle.sens_shadow_prices(p, res.T).tolist() == [-1.0]
