@@ -28,6 +28,7 @@ Extra objects on the same JSON line (rank 0 unless stated):
 import argparse
 import json
 import os
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # cpu_baseline's OpenMP team must not spin
 import sys
 import time
 
@@ -70,6 +71,12 @@ def pmc_traffic(R, C):
         if k.endswith(f"@grid{grid}"):
             return v["hbm_bytes_per_launch"]
     return None
+
+
+def progress(msg):
+    """One line per leg on stderr: the GPU pool kills runs that stay silent for minutes."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -154,6 +161,7 @@ def main():
         assert status == 0, f"solve ended with status {status}"
         return st
 
+    progress("config 2 solves")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -193,6 +201,7 @@ def main():
     }
 
     if not args.no_extras:
+        progress(f"value leg done ({dt_s:.1f} s); B&B leg (config 4)")
         # ---- config 4: sharded branch and bound (all ranks) -------------------------------------------
         cb, Ab, relb, bb = synth.binary_ip(512, 256)
         pb = L.LPProblem.from_arrays(0, cb, Ab, relb, bb)
@@ -227,6 +236,7 @@ def main():
                            "nodes_per_s": lpw_total / tw_max, "lp_relaxations": lpw_total, "pivots": pivw_total,
                            "pivots_per_node": pivw_total / max(lpw_total, 1), "wall_s": tw_max,
                            "incumbent": rw.OptimalValue if rw.OptimalValue > -1e300 else None}
+        progress("knapsack leg (config 5)")
         # ---- config 5: sharded knapsack (all ranks) ---------------------------------------------------
         pk, wk, capk = synth.knapsack(100_000)
         kp = L.LPProblem(L.Sense.Max, pk.tolist(), [L.Constraint(wk.tolist(), L.Rel.LE, capk)])
@@ -244,6 +254,7 @@ def main():
                            "relaxations_per_s": rel_total / tk_max, "wall_s": tk_max, "incumbent": rk.OptimalValue}
 
     if rank == 0 and not args.no_extras:
+        progress("roofline legs")
         # ---- measured device-to-device copy bandwidth of THIS box (report both peaks) ------
         src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
@@ -294,6 +305,7 @@ def main():
                                     "algorithmic_bytes_per_launch": halg,
                                     "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}
         hd.close()
+        progress("revised leg (config 3)")
         # ---- config 3: revised simplex m=4096 n=8192 -----------------------------------------------------
         c3, A3, b3 = synth.dense_lp(4096, 8192)
         rv = L.DeviceRevised(A3, -c3, b3)
@@ -315,6 +327,7 @@ def main():
                           "refactor_note": "K7' = the reference's Invert (4096 Gauss-Jordan steps x 16*m*2m bytes), "
                                            "which the reference runs EVERY iteration; the engine runs it on demand"}
         rv.close()
+        progress("CPU baselines")
         # ---- CPU baseline: oracle (C port of the reference loops), 1 core -------------------------------
         if world == 1:
             from oracle import oracle as O
@@ -325,8 +338,11 @@ def main():
             out["cpu_baseline"] = {"value": len(tr_c) / cpu_s, "unit": "pivots/s", "cores": 1, "kind": "port",
                                    "sample": f"all {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
                                              f"(gcc -O2 -ffp-contract=off, scalar), {cpu_s:.1f} s"}
+            progress(f"CPU 1-core done ({cpu_s:.1f} s); all-cores baseline")
             # courtesy strong baseline: the same loop with Pivot's rows spread over all host cores
-            ncores = len(os.sched_getaffinity(0))
+            # the box grants 16 CPUs per GPU whatever the affinity mask says; oversubscribed OpenMP
+            # teams spin in their barriers, so cap the team and make idle threads sleep
+            ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
             Tm, bm = T.copy(), basis.copy()
             t2 = time.perf_counter()
             st_m, tr_m = O.primal_tableau(Tm, bm, max_iter=args.cpu_sample_pivots, threads=ncores)
@@ -335,6 +351,7 @@ def main():
             out["cpu_baseline"]["all_cores"] = {"value": len(tr_m) / mt_s, "unit": "pivots/s", "cores": ncores,
                                                 "sample": f"same {len(tr_m)} pivots, oracle/primal_mt.c (OpenMP over "
                                                           f"the rows of Pivot, bit-identical), {mt_s:.1f} s"}
+            progress(f"all-cores done ({mt_s:.1f} s); revised CPU sample")
             # reference-faithful revised path (Invert every iteration), bounded: 3 iterations at m=1024
             c1, A1, b1 = synth.dense_lp(1024, 2048)
             t2 = time.perf_counter()
@@ -344,6 +361,7 @@ def main():
             out["cpu_baseline"]["revised_sample"] = (f"first {len(rr_c.trace)} iterations at m=1024 n=2048, oracle/revised.c "
                                                      f"(full Invert per iteration as the reference), {cr:.1f} s; "
                                                      "config 3 (m=4096) costs 64x the flops per iteration -- extrapolation, not measured")
+            progress("knapsack / B&B CPU samples")
             # bounded CPU samples of the other legs, for the record
             t2 = time.perf_counter()
             rk_c = O.knapsack_solve(O.Problem(O.MAX, pk, wk.reshape(1, -1), [O.LE], [capk]), max_nodes=4000)

@@ -77,6 +77,9 @@ typedef struct lpx_run_opts {
     int    batch;      /* pivots enqueued between host polls of the device state; 0 = default */
     int    use_graph;  /* 1 = replay a captured hipGraph per batch, 0 = eager launches */
     int    profile;    /* 1 = eager, every update kernel bracketed by HIP events (roofline leg) */
+    int    resident;   /* primal loop with the whole tableau resident in LDS (one persistent workgroup per CU,
+                          csrc/lpx_resident.hip) when it fits the chip: 0 = automatic, 1 = require it
+                          (LPX_EINVAL when the tableau does not fit), -1 = never (streaming kernels) */
 } lpx_run_opts;
 
 void lpx_default_opts(lpx_run_opts* o, int dual);

@@ -39,7 +39,7 @@ class Stats(C.Structure):
 class RunOpts(C.Structure):
     _fields_ = [("eps", C.c_double), ("ratio_tol", C.c_double), ("max_iter", C.c_int),
                 ("fdf_guard", C.c_int), ("cleanup", C.c_int), ("batch", C.c_int),
-                ("use_graph", C.c_int), ("profile", C.c_int)]
+                ("use_graph", C.c_int), ("profile", C.c_int), ("resident", C.c_int)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)

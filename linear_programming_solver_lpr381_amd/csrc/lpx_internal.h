@@ -22,7 +22,7 @@ struct DevState {
     int qn;              // lookahead: entering column of the NEXT pivot (-1 = none), see lpx_select_la
     int c0n;             // multi-workgroup select: start column of the next forced search
     int qn_valid;        // multi-workgroup select: 1 = `qn` above overrides the partial reduction
-    int pad[4];
+    int pad[4];          // pad[0]: revised path's Nidx order counter; pad[1]: resident loop abort flag
 };
 
 enum { MODE_PRIMAL = 0, MODE_DUAL = 1, MODE_FORCED = 2 };
@@ -73,6 +73,13 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
                              int32_t* basis, hipStream_t s);
 hipError_t kernels_init();          // one-time function attributes
+// resident primal loop (lpx_resident.hip)
+hipError_t resident_init();
+int resident_plan(int R, int C, int ld, int* grid, int* rpw, size_t* lds);      // 0 = does not fit on chip
+hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int rpw, size_t lds, int mcap,
+                                  int32_t* basis, int32_t* trace, int trace_cap, DevState* st,
+                                  unsigned long long* xr, unsigned long long* xp, unsigned* xgen,
+                                  double eps, double tol, int max_iter, int chunk, hipStream_t s);
 
 void set_error(const std::string& msg);
 int ensure_device();                // binds a device and sets kernel attributes once

@@ -27,7 +27,7 @@ int ensure_device()
         g_device = 0;
         LPX_HIP_TRY(hipSetDevice(0));
     }
-    std::call_once(g_init_once, [] { g_init_err = kernels_init(); });
+    std::call_once(g_init_once, [] { g_init_err = kernels_init(); if (g_init_err == hipSuccess) g_init_err = resident_init(); });
     if (g_init_err != hipSuccess) {
         set_error(std::string("kernel attribute setup failed: ") + hipGetErrorString(g_init_err));
         return LPX_EDEVICE;

@@ -1,0 +1,283 @@
+// lpx_resident.hip -- the primal simplex loop with the WHOLE tableau resident on chip.
+//
+// When the tableau fits the chip's aggregate LDS (256 CUs x 160 KB = 40 MB; config 2's 1025 x 3073 tableau
+// is 25 MB) the streaming path is the wrong shape: it moves 16*R*C bytes through HBM / Infinity Cache per
+// pivot and pays two kernel boundaries, although nothing but the pivot row and one ratio per row ever has
+// to leave a CU.  Here one persistent workgroup per CU keeps `rpw` consecutive constraint rows in its LDS for
+// the whole solve, plus its own replica of the objective row (every workgroup updates it redundantly, so the
+// entering column of ChooseEntering, Models/PrimalSimplex.cs:205-220, is known everywhere without any
+// communication).  Per pivot exactly two things cross CUs, both through self-validating tagged granules in
+// global memory (no grid barrier, no fence):
+//
+//   1. ChooseLeaving (Models/PrimalSimplex.cs:222-243): each workgroup publishes the ratio rhs/a of its rows
+//      (+inf when a <= eps); every workgroup gathers all m ratios and runs the exact hysteresis scan itself.
+//   2. Pivot (Models/PrimalSimplex.cs:245-257): the owner of row r divides it by the pivot (true division) and
+//      publishes it; every workgroup gathers it and updates its rows (`t - f*p`, multiply and subtract rounded
+//      separately) -- bit for bit the arithmetic of lpx_update.
+//
+// Granule: a double travels as two naturally aligned 8-byte words {32 data bits, 32-bit generation tag},
+// each written by ONE write-through (sc1) store and read by sc1 loads that bypass the reader's L1; a reader
+// accepts a value only when both tags equal the generation it waits for, so no ordering between the words or
+// against any flag is needed.  Exchange buffers are double-buffered on the generation's parity: a workgroup can
+// run at most one exchange ahead of the slowest one (it needs that one's ratio to get the next pivot row).
+// Every wait is bounded (RS_SPIN_MAX polls); on expiry the workgroup raises the abort flag in the state
+// record and leaves without writing its rows back, and the host reports LPX_EDEVICE.
+#include "lpx_block.h"
+
+namespace lpx {
+
+static constexpr int RS_NT = 1024;
+static constexpr unsigned RS_SPIN_MAX = 1u << 21;
+static constexpr int RS_FETCH = 4;              // granule pairs in flight per lane while gathering
+
+struct ResParams {
+    double* T; int ld; int R; int C;            // live shape
+    int rpw;                                    // constraint rows per workgroup
+    int mcap;                                   // rows of one parity half of xr
+    int32_t* basis; int32_t* trace; int trace_cap;
+    DevState* st;
+    unsigned long long* xr;                     // [2][mcap][2]  ratio granules
+    unsigned long long* xp;                     // [2][ld][2]    pivot-row granules
+    unsigned* xgen;                             // generation counter, survives launches
+    double eps, tol;
+    int max_iter, chunk;
+};
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void rs_publish(u64* g, double v, unsigned gen)
+{
+    const u64 bits = (u64)__double_as_longlong(v);
+    const u64 tag = (u64)gen << 32;
+    __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Gathers count (<= RS_FETCH) granule pairs g[idx[u]] of generation `gen`; all loads of a round are in flight
+// together.  Returns false when the wait expired.
+__device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int count, unsigned gen, double* out)
+{
+    unsigned pending = (1u << count) - 1u;
+    for (unsigned spin = 0; spin < RS_SPIN_MAX && pending; ++spin) {
+        u64 w0[RS_FETCH], w1[RS_FETCH];
+#pragma unroll
+        for (int u = 0; u < RS_FETCH; ++u) {
+            const int k = idx[u < count ? u : 0];
+            w0[u] = __hip_atomic_load(g + 2 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1[u] = __hip_atomic_load(g + 2 * (size_t)k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < RS_FETCH; ++u) {
+            if ((pending >> u) & 1u) {
+                if ((unsigned)(w0[u] >> 32) == gen && (unsigned)(w1[u] >> 32) == gen) {
+                    out[u] = __longlong_as_double((long long)((w1[u] << 32) | (w0[u] & 0xffffffffull)));
+                    pending &= ~(1u << u);
+                }
+            }
+        }
+        if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
+    }
+    return pending == 0;
+}
+
+struct LdsRatio {
+    const double* v;
+    __device__ __forceinline__ double den(int i) const { return v[i]; }
+    __device__ __forceinline__ double num(int) const { return 0.0; }
+    __device__ __forceinline__ double value(double a, double) const { return a; }
+};
+
+__global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
+{
+    extern __shared__ __align__(16) double rs_lds[];
+    __shared__ double s_v[RS_NT / 64];
+    __shared__ int s_i[RS_NT / 64];
+    __shared__ int s_out;
+
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x, w = blockIdx.x;
+    const int ld = P.ld, C = P.C, m = P.R - 1, rpw = P.rpw;
+    const int row0 = w * rpw;
+    const int nloc = max(0, min(rpw, m - row0));
+    double* tile = rs_lds;                      // [rpw][ld]
+    double* obj = tile + (size_t)rpw * ld;      // [ld]   replica of the objective row
+    double* prow = obj + ld;                    // [ld]   pivot row of the current pivot
+    double* ratios = prow + ld;                 // [m]    gathered ratios
+    double* fac = ratios + ((m + 1) & ~1);      // [rpw+1] column factors of the local rows, then of obj
+
+    for (int i = 0; i < nloc; ++i) {
+        const double* src = P.T + (size_t)(row0 + i) * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = *reinterpret_cast<const double2*>(src + j);
+    }
+    {
+        const double* src = P.T + (size_t)m * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            *reinterpret_cast<double2*>(obj + j) = *reinterpret_cast<const double2*>(src + j);
+            *reinterpret_cast<double2*>(prow + j) = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
+    int iter = st->iter;
+    unsigned gen = *P.xgen;
+    int status = LPX_RUNNING;
+    bool hung = false;
+    int r = -1, qlast = -1;
+    // ChooseEntering on the initial objective row, :205-220
+    int q = block_first_min_below<RS_NT>(obj, 1, C - 1, P.eps, s_v, s_i);
+
+    for (int k = 0; k < P.chunk; ++k) {
+        if (iter >= P.max_iter) { status = LPX_ITER_LIMIT; break; }            // :95-96
+        if (q < 0) { status = LPX_OPTIMAL; break; }                             // :99
+        ++gen;
+        const int par = (int)(gen & 1u);
+        // ---- exchange 1: ratios of the local rows, :229-233 ----------------------------------------
+        if (t < nloc) {
+            const double a = tile[(size_t)t * ld + q];
+            const double rhs = tile[(size_t)t * ld + C - 1];
+            fac[t] = a;
+            rs_publish(P.xr + 2 * ((size_t)par * P.mcap + row0 + t), a > P.eps ? rhs / a : __builtin_inf(), gen);
+        }
+        if (t == RS_NT - 1) fac[rpw] = obj[q];
+        int fail = 0;
+        for (int base = t; base < m; base += RS_NT * RS_FETCH) {
+            int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < RS_FETCH; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < m) cnt = u + 1; }
+            if (!rs_gather(P.xr + 2 * (size_t)par * P.mcap, idx, cnt, gen, val)) fail = 1;
+#pragma unroll
+            for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) ratios[idx[u]] = val[u];
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+        // the hysteresis scan of :234-241, identical in every workgroup
+        r = block_hysteresis_argmin(m, P.tol, LdsRatio{ratios}, &s_out);
+        if (r < 0) { status = LPX_UNBOUNDED; break; }                          // :102-106
+        // ---- exchange 2: the normalised pivot row, :247-249 ----------------------------------------
+        const int owner = r / rpw, rl = r - owner * rpw;
+        u64* xp = P.xp + 2 * (size_t)par * ld;
+        if (w == owner) {
+            double* prw = tile + (size_t)rl * ld;
+            const double piv = prw[q];
+            __syncthreads();
+            for (int j = t; j < C; j += RS_NT) {
+                const double p = prw[j] / piv;
+                rs_publish(xp + 2 * (size_t)j, p, gen);
+                prw[j] = p;
+                prow[j] = p;
+            }
+        } else {
+            for (int base = t; base < C; base += RS_NT * RS_FETCH) {
+                int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < RS_FETCH; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < C) cnt = u + 1; }
+                if (!rs_gather(xp, idx, cnt, gen, val)) fail = 1;
+#pragma unroll
+                for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) prow[idx[u]] = val[u];
+            }
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+        // ---- rank-1 update of the local rows and of the objective replica, :250-256 -------------------
+        const double fobj = fac[rpw];
+        const int skip = (w == owner) ? rl : -1;
+        MinIdx best; best.v = -P.eps; best.i = INT_MAX;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + j);
+            double2 o = *reinterpret_cast<double2*>(obj + j);
+            double prod = fobj * p.x; o.x = o.x - prod;
+            prod = fobj * p.y; o.y = o.y - prod;
+            *reinterpret_cast<double2*>(obj + j) = o;
+            if (j < C - 1 && o.x < best.v) { best.v = o.x; best.i = j; }
+            if (j + 1 < C - 1 && o.y < best.v) { best.v = o.y; best.i = j + 1; }
+            for (int i = 0; i < nloc; ++i) {
+                if (i == skip) continue;
+                const double f = fac[i];
+                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                prod = f * p.x; v.x = v.x - prod;
+                prod = f * p.y; v.y = v.y - prod;
+                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+            }
+        }
+        if (w == 0 && t == 0) {
+            P.basis[r] = q;                                                     // :110
+            if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        }
+        qlast = q;
+        ++iter;
+        best = block_min_idx<RS_NT>(best, s_v, s_i);                            // next ChooseEntering
+        q = best.i == INT_MAX ? -1 : best.i;
+        __syncthreads();
+    }
+
+    if (hung) {
+        if (t == 0) atomicOr(&st->pad[1], 1);
+        return;
+    }
+    for (int i = 0; i < nloc; ++i) {
+        double* dst = P.T + (size_t)(row0 + i) * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(tile + (size_t)i * ld + j);
+    }
+    if (w == 0) {
+        double* dst = P.T + (size_t)m * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(obj + j);
+        if (t == 0) {
+            st->status = status; st->iter = iter; st->primal_count = iter;
+            st->r = r; st->q = qlast;
+            *P.xgen = gen;
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+static size_t resident_lds_bytes(int R, int C, int ld, int rpw)
+{
+    const int m = R - 1;
+    return sizeof(double) * ((size_t)(rpw + 2) * ld + ((m + 1) & ~1) + (size_t)rpw + 2);
+}
+
+// Picks the grid for a live shape; returns 0 when the tableau does not fit on chip.
+int resident_plan(int R, int C, int ld, int* grid, int* rpw, size_t* lds)
+{
+    static int cus = 0;
+    static size_t lds_max = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+        lds_max = 160 * 1024 - 1024;            // one workgroup may take the CU's whole LDS (gfx950: 160 KB)
+    }
+    const int m = R - 1;
+    if (m < 1 || cus < 1) return 0;
+    const int g = m < cus ? m : cus;
+    const int rp = (m + g - 1) / g;
+    const int gg = (m + rp - 1) / rp;
+    const size_t need = resident_lds_bytes(R, C, ld, rp);
+    if (need > lds_max) return 0;
+    *grid = gg; *rpw = rp; *lds = need;
+    return 1;
+}
+
+hipError_t resident_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_primal),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int rpw, size_t lds, int mcap,
+                                  int32_t* basis, int32_t* trace, int trace_cap, DevState* st,
+                                  unsigned long long* xr, unsigned long long* xp, unsigned* xgen,
+                                  double eps, double tol, int max_iter, int chunk, hipStream_t s)
+{
+    ResParams p;
+    p.T = T; p.ld = ld; p.R = R; p.C = C; p.rpw = rpw; p.mcap = mcap;
+    p.basis = basis; p.trace = trace; p.trace_cap = trace_cap; p.st = st;
+    p.xr = xr; p.xp = xp; p.xgen = xgen; p.eps = eps; p.tol = tol; p.max_iter = max_iter; p.chunk = chunk;
+    hipLaunchKernelGGL(lpx_resident_primal, dim3(grid), dim3(RS_NT), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lpx

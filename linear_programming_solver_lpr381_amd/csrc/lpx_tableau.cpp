@@ -40,6 +40,8 @@ struct lpx_tableau {
     int g_batch = 0;
     std::string g_key;
     std::vector<hipEvent_t> events;
+    // resident primal loop: exchange buffers (tagged granules) and the generation counter
+    unsigned long long* xr = nullptr; unsigned long long* xp = nullptr; unsigned* xgen = nullptr;
 };
 
 static void drop_graph(lpx_tableau* t)
@@ -98,6 +100,7 @@ void lpx_default_opts(lpx_run_opts* o, int dual)
     static const bool no_graph = [] { const char* e = std::getenv("LPX_GRAPH"); return e && e[0] == '0'; }();
     o->use_graph = no_graph ? 0 : 1;     // LPX_GRAPH=0: diagnostic switch to eager launches
     o->profile = 0;
+    o->resident = 0;
 }
 
 int lpx_tableau_create(int R, int C, lpx_tableau** out)
@@ -165,6 +168,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws); hipFree(t->part_v); hipFree(t->part_i); hipFree(t->us);
     hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf); hipFree(t->shape);
+    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen);
     if (t->shape_h) hipHostFree(t->shape_h);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
     if (t->hst) hipHostFree(t->hst);
@@ -331,6 +335,63 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
     return p;
 }
 
+// Resident primal loop: one launch runs up to `chunk` pivots with the tableau in LDS; the host only polls the
+// 64-byte state record between launches (and fires the pivot callbacks from the trace).
+int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* stats,
+                 int grid, int rpw, size_t lds)
+{
+    const int mcap = t->Rcap;
+    if (!t->xr) {
+        const size_t rb = sizeof(unsigned long long) * 4 * (size_t)mcap, pb = sizeof(unsigned long long) * 4 * (size_t)t->ld;
+        LPX_HIP_TRY(hipMalloc((void**)&t->xr, rb));
+        LPX_HIP_TRY(hipMalloc((void**)&t->xp, pb));
+        LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
+        LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, rb, t->stream));
+        LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, pb, t->stream));
+        LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
+    }
+    DevState init; std::memset(&init, 0, sizeof(init));
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
+    *t->hst = init;
+    LPX_HIP_TRY(hipMemcpyAsync(t->st, t->hst, sizeof(DevState), hipMemcpyHostToDevice, t->stream));
+    const int chunk = cb ? (o->batch > 0 ? o->batch : 256) : (1 << 30);
+    lpx_stats local; std::memset(&local, 0, sizeof(local));
+    const double t0 = now_ms();
+    int fired = 0, status = LPX_RUNNING;
+    for (long long launches = 0; status == LPX_RUNNING; ++launches) {
+        if (launches > (long long)o->max_iter + 4) { set_error("resident loop: launch budget exhausted while still running"); return LPX_ITER_LIMIT; }
+        LPX_HIP_TRY(launch_resident_primal(t->T, t->ld, t->R, t->C, grid, rpw, lds, mcap, t->basis, t->trace, t->trace_cap,
+                                           t->st, t->xr, t->xp, t->xgen, o->eps, o->ratio_tol, o->max_iter, chunk, t->stream));
+        local.launches++;
+        LPX_HIP_TRY(hipMemcpyAsync(t->hst, t->st, sizeof(DevState), hipMemcpyDeviceToHost, t->stream));
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->hst->pad[1]) {
+            // a bounded wait expired: some workgroup was not resident or died; rows in HBM are those of the last
+            // completed launch.  Clear the exchange buffers so that no stale generation can ever match.
+            hipMemsetAsync(t->xr, 0, sizeof(unsigned long long) * 4 * (size_t)mcap, t->stream);
+            hipMemsetAsync(t->xp, 0, sizeof(unsigned long long) * 4 * (size_t)t->ld, t->stream);
+            hipStreamSynchronize(t->stream);
+            set_error("resident loop: an exchange wait expired (workgroups not co-resident?)");
+            return LPX_EDEVICE;
+        }
+        status = t->hst->status;
+        const int done = t->hst->iter;
+        if (cb && done > fired) {
+            const int lo = fired, hi = done < t->trace_cap ? done : t->trace_cap;
+            if (hi > lo) {
+                std::vector<int32_t> tr(2 * (size_t)(hi - lo));
+                LPX_HIP_TRY(hipMemcpy(tr.data(), t->trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
+                for (int k = lo; k < hi; ++k) cb(user, k + 1, tr[2 * (k - lo)], tr[2 * (k - lo) + 1]);
+            }
+        }
+        fired = done;
+    }
+    local.loop_ms = now_ms() - t0;
+    local.pivots = t->hst->iter;
+    if (stats) { const double h2d = stats->h2d_ms, d2h = stats->d2h_ms; *stats = local; stats->h2d_ms = h2d; stats->d2h_ms = d2h; }
+    return status;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -477,6 +538,13 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
     if (!t) { set_error("lpx_primal_run: null tableau"); return LPX_EINVAL; }
     lpx_run_opts d; if (!o) { lpx_default_opts(&d, 0); o = &d; }
     if (t->R < 2) { set_error("lpx_primal_run: tableau needs at least one constraint row"); return LPX_EINVAL; }
+    // Tableau small enough to live on chip: persistent workgroups, no per-pivot HBM traffic (lpx_resident.hip).
+    static const bool res_env = [] { const char* e = std::getenv("LPX_RESIDENT"); return !(e && e[0] == '0'); }();
+    if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
+        int grid = 0, rpw = 0; size_t lds = 0;
+        if (resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds)) return run_resident(t, o, cb, user, st, grid, rpw, lds);
+        if (o->resident > 0) { set_error("lpx_primal_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
+    }
     SelParams p = base_params(t, o, MODE_PRIMAL);
     return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st);
 }

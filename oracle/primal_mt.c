@@ -28,6 +28,7 @@ int orc_primal_tableau_mt(double* T, int R, int C, int32_t* basis, double eps, i
                           int32_t* trace, int* n_pivots, int threads)
 {
     if (threads > 0) omp_set_num_threads(threads);
+    omp_set_dynamic(0);
     int iter = 1, np = 0, status;
     for (;;) {
         if (iter > max_iter) { status = ORC_ITER_LIMIT; break; }

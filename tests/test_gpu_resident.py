@@ -1,0 +1,116 @@
+"""GPU parity of the on-chip resident primal loop (csrc/lpx_resident.hip: tableau in LDS, one persistent
+workgroup per CU, tagged-granule exchange) against the CPU oracle AND against the streaming kernels:
+bit-exact tableaux, traces, bases and statuses."""
+import numpy as np
+import pytest
+
+from linear_programming_solver_lpr381_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _run(gpu, T, basis, **kw):
+    with gpu.DeviceTableau.from_host(T, basis) as dt:
+        status, st = dt.primal_run(**kw)
+        Tg, bg = dt.download()
+        return status, st, Tg, bg, dt.trace()
+
+
+# m below, at and above the CU count (1 row per workgroup / 2 rows per workgroup / ragged last workgroup),
+# odd widths (padding lanes), one-row and one-column problems
+@pytest.mark.parametrize("m,n,seed", [(1, 1, 1), (1, 7, 2), (3, 2, 3), (17, 9, 4), (64, 100, 5), (255, 300, 6),
+                                      (256, 256, 7), (257, 401, 8), (300, 700, 9), (513, 1100, 10)])
+def test_resident_matches_oracle_and_streaming_bitwise(gpu, oracle, m, n, seed):
+    c, A, b = synth.dense_lp(m, n, seed=seed)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    Tr, br = T.copy(), basis.copy()
+    st_ref, tr_ref = oracle.primal_tableau(Tr, br)
+    s1, st1, T1, b1, tr1 = _run(gpu, T, basis, resident=1)
+    s0, st0, T0, b0, tr0 = _run(gpu, T, basis, resident=-1)
+    assert s1 == st_ref == s0
+    assert tr1.tolist() == tr_ref.tolist() == tr0.tolist()
+    assert b1.tolist() == br.tolist()
+    assert np.array_equal(_bits(T1), _bits(Tr)) and np.array_equal(_bits(T0), _bits(Tr))
+    assert st1["pivots"] == len(tr_ref) and st1["launches"] == 1
+
+
+def test_resident_config2_full_solve_bitwise(gpu, oracle):
+    c, A, b = synth.dense_lp(1024, 2048)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    Tr, br = T.copy(), basis.copy()
+    st_ref, tr_ref = oracle.primal_tableau(Tr, br)
+    s1, st1, T1, b1, tr1 = _run(gpu, T, basis, resident=1)
+    assert s1 == st_ref == 0 and tr1.tolist() == tr_ref.tolist() and b1.tolist() == br.tolist()
+    assert np.array_equal(_bits(T1), _bits(Tr))
+
+
+def test_resident_callbacks_chunks_and_restarts(gpu, oracle):
+    c, A, b = synth.dense_lp(96, 150, seed=21)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    Tr, br = T.copy(), basis.copy()
+    st_ref, tr_ref = oracle.primal_tableau(Tr, br)
+    events = []
+    with gpu.DeviceTableau.from_host(T, basis) as dt:
+        dt.snapshot()
+        status, st = dt.primal_run(resident=1, batch=32, cb=lambda it, r, q: events.append((it, r, q)))
+        assert status == 0 and st["launches"] == -(-(len(tr_ref) + 1) // 32)
+        assert [(e[1], e[2]) for e in events] == [tuple(x) for x in tr_ref.tolist()]
+        assert [e[0] for e in events] == list(range(1, len(tr_ref) + 1))
+        T1, _ = dt.download()
+        assert np.array_equal(_bits(T1), _bits(Tr))
+        for _ in range(3):                       # generations keep counting across runs of one handle
+            dt.restore()
+            status, st = dt.primal_run(resident=1)
+            T2, b2 = dt.download()
+            assert status == 0 and np.array_equal(_bits(T2), _bits(Tr)) and b2.tolist() == br.tolist()
+        dt.restore()
+        status, st = dt.primal_run(resident=-1)  # and the streaming path still starts cleanly afterwards
+        T3, _ = dt.download()
+        assert np.array_equal(_bits(T3), _bits(Tr))
+
+
+def test_resident_terminal_statuses(gpu, oracle):
+    # unbounded: max x1, -x1 + x2 <= 1
+    T, basis = synth.primal_tableau_from(np.array([1.0, 0.0]), np.array([[-1.0, 1.0]]), np.array([1.0]))
+    Tr, br = T.copy(), basis.copy()
+    st_ref, _ = oracle.primal_tableau(Tr, br)
+    s, _, Tg, _, _ = _run(gpu, T, basis, resident=1)
+    assert s == st_ref == 1 and np.array_equal(_bits(Tg), _bits(Tr))
+    # iteration limit: the k pivots are done, then the limit fires before ChooseEntering (:95-98)
+    c, A, b = synth.dense_lp(40, 60, seed=2)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    for k in (0, 1, 5):
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=k)
+        s, st, Tg, bg, tr = _run(gpu, T, basis, resident=1, max_iter=k)
+        assert s == st_ref == 3 and tr.tolist() == tr_ref.tolist() and np.array_equal(_bits(Tg), _bits(Tr))
+    # already optimal: no pivot, one launch
+    T, basis = synth.primal_tableau_from(np.array([-1.0, -2.0]), np.array([[1.0, 1.0]]), np.array([3.0]))
+    s, st, Tg, _, tr = _run(gpu, T, basis, resident=1)
+    assert s == 0 and len(tr) == 0 and np.array_equal(_bits(Tg), _bits(T))
+
+
+def test_resident_degenerate_ties_follow_the_hysteresis_scan(gpu, oracle):
+    g = np.random.default_rng(5)
+    for trial in range(6):
+        m, n = 40, 30
+        A = g.integers(0, 4, size=(m, n)).astype(float)
+        b = g.integers(0, 3, size=m).astype(float)            # many zero and equal ratios
+        c = g.integers(1, 5, size=n).astype(float)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=500)
+        s, _, Tg, bg, tr = _run(gpu, T, basis, resident=1, max_iter=500)
+        assert s == st_ref and tr.tolist() == tr_ref.tolist(), trial
+        assert np.array_equal(_bits(Tg), _bits(Tr))
+
+
+def test_resident_required_but_too_large(gpu):
+    T = synth.raw_tableau(2049, 4100, seed=3)                  # 67 MB: does not fit 256 x 160 KB
+    with gpu.DeviceTableau.from_host(T) as dt:
+        with pytest.raises(gpu.LpxError, match="does not fit"):
+            dt.primal_run(resident=1, max_iter=1)
