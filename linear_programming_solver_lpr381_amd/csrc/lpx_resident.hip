@@ -45,39 +45,69 @@ struct ResParams {
 
 typedef unsigned long long u64;
 
+#ifdef LPX_STAMPS
+#define RS_T0 unsigned long long rs_prev_ = __builtin_amdgcn_s_memtime();
+#define RS_T(slot) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1 ? 1 : 0)) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); P.xp[4 * (size_t)P.ld + (slot)] += n_ - rs_prev_; rs_prev_ = n_; } } while (0)
+#else
+#define RS_T0
+#define RS_T(slot) do {} while (0)
+#endif
+
+typedef unsigned rs_u4 __attribute__((ext_vector_type(4)));
+
+// One double = one 16-byte granule pair {lo32, tag, hi32, tag}: a single write-through dwordx4 store, a single
+// dwordx4 sc1 load.  Each 8-byte half validates itself, so it does not matter whether the fabric keeps the 16
+// bytes together.
 __device__ __forceinline__ void rs_publish(u64* g, double v, unsigned gen)
 {
     const u64 bits = (u64)__double_as_longlong(v);
-    const u64 tag = (u64)gen << 32;
-    __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rs_u4 w;
+    w.x = (unsigned)bits; w.y = gen; w.z = (unsigned)(bits >> 32); w.w = gen;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(g), "v"(w) : "memory");
 }
 
 // Gathers count (<= RS_FETCH) granule pairs g[idx[u]] of generation `gen`; all loads of a round are in flight
 // together.  Returns false when the wait expired.
 __device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int count, unsigned gen, double* out)
 {
+    static_assert(RS_FETCH == 4, "the load group below is written for four granule pairs");
     unsigned pending = (1u << count) - 1u;
+    const u64* p0 = g + 2 * (size_t)idx[0];
+    const u64* p1 = g + 2 * (size_t)idx[count > 1 ? 1 : 0];
+    const u64* p2 = g + 2 * (size_t)idx[count > 2 ? 2 : 0];
+    const u64* p3 = g + 2 * (size_t)idx[count > 3 ? 3 : 0];
     for (unsigned spin = 0; spin < RS_SPIN_MAX && pending; ++spin) {
-        u64 w0[RS_FETCH], w1[RS_FETCH];
+        rs_u4 w[RS_FETCH];
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                     : "memory");
 #pragma unroll
         for (int u = 0; u < RS_FETCH; ++u) {
-            const int k = idx[u < count ? u : 0];
-            w0[u] = __hip_atomic_load(g + 2 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w1[u] = __hip_atomic_load(g + 2 * (size_t)k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int u = 0; u < RS_FETCH; ++u) {
-            if ((pending >> u) & 1u) {
-                if ((unsigned)(w0[u] >> 32) == gen && (unsigned)(w1[u] >> 32) == gen) {
-                    out[u] = __longlong_as_double((long long)((w1[u] << 32) | (w0[u] & 0xffffffffull)));
-                    pending &= ~(1u << u);
-                }
+            if (((pending >> u) & 1u) && w[u].y == gen && w[u].w == gen) {
+                out[u] = __longlong_as_double((long long)(((u64)w[u].z << 32) | (u64)w[u].x));
+                pending &= ~(1u << u);
             }
         }
         if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
     }
     return pending == 0;
+}
+
+// Waits until one granule pair carries generation `gen` (same address in every lane: one request per wave).
+__device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
+{
+    for (unsigned spin = 0; spin < RS_SPIN_MAX; ++spin) {
+        rs_u4 w;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(g) : "memory");
+        if (w.y == gen && w.w == gen) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
 }
 
 struct LdsRatio {
@@ -104,7 +134,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     double* obj = tile + (size_t)rpw * ld;      // [ld]   replica of the objective row
     double* prow = obj + ld;                    // [ld]   pivot row of the current pivot
     double* ratios = prow + ld;                 // [m]    gathered ratios
-    double* fac = ratios + ((m + 1) & ~1);      // [rpw+1] column factors of the local rows, then of obj
+    double* fac0 = ratios + ((m + 1) & ~1);     // [rpw+1] column factors of the local rows, then of obj ...
+    double* fac1 = fac0 + ((rpw + 2) & ~1);     // ... ping-pong: the next pivot's are written while this one's are in use
 
     for (int i = 0; i < nloc; ++i) {
         const double* src = P.T + (size_t)(row0 + i) * ld;
@@ -127,20 +158,27 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     int r = -1, qlast = -1;
     // ChooseEntering on the initial objective row, :205-220
     int q = block_first_min_below<RS_NT>(obj, 1, C - 1, P.eps, s_v, s_i);
+    double* fac = fac0;                         // factors of the pivot about to be made
+    double* facn = fac1;
+    // ratios of the first pivot of this launch (:229-233); later ones are published by the lookahead below
+    if (q >= 0 && iter < P.max_iter && P.chunk > 0) {
+        if (t < nloc) {
+            const double a = tile[(size_t)t * ld + q];
+            const double rhs = tile[(size_t)t * ld + C - 1];
+            fac[t] = a;
+            rs_publish(P.xr + 2 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t), a > P.eps ? rhs / a : __builtin_inf(), gen + 1u);
+        }
+        if (t == RS_NT - 1) fac[rpw] = obj[q];
+    }
+    __syncthreads();
 
+    RS_T0
     for (int k = 0; k < P.chunk; ++k) {
         if (iter >= P.max_iter) { status = LPX_ITER_LIMIT; break; }            // :95-96
         if (q < 0) { status = LPX_OPTIMAL; break; }                             // :99
         ++gen;
         const int par = (int)(gen & 1u);
-        // ---- exchange 1: ratios of the local rows, :229-233 ----------------------------------------
-        if (t < nloc) {
-            const double a = tile[(size_t)t * ld + q];
-            const double rhs = tile[(size_t)t * ld + C - 1];
-            fac[t] = a;
-            rs_publish(P.xr + 2 * ((size_t)par * P.mcap + row0 + t), a > P.eps ? rhs / a : __builtin_inf(), gen);
-        }
-        if (t == RS_NT - 1) fac[rpw] = obj[q];
+        // ---- exchange 1: gather the ratios of all rows ------------------------------------------------
         int fail = 0;
         for (int base = t; base < m; base += RS_NT * RS_FETCH) {
             int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
@@ -151,9 +189,16 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
             for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) ratios[idx[u]] = val[u];
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
-        // the hysteresis scan of :234-241, identical in every workgroup
-        r = block_hysteresis_argmin(m, P.tol, LdsRatio{ratios}, &s_out);
+        RS_T(1);
+        // the hysteresis scan of :234-241: one wave of every workgroup runs it on the same data
+        if ((t >> 6) == 0) {
+            const int win = wave_hysteresis_argmin(m, P.tol, LdsRatio{ratios});
+            if (t == 0) s_out = win;
+        }
+        __syncthreads();
+        r = s_out;
         if (r < 0) { status = LPX_UNBOUNDED; break; }                          // :102-106
+        RS_T(2);
         // ---- exchange 2: the normalised pivot row, :247-249 ----------------------------------------
         const int owner = r / rpw, rl = r - owner * rpw;
         u64* xp = P.xp + 2 * (size_t)par * ld;
@@ -168,6 +213,9 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
                 prow[j] = p;
             }
         } else {
+            // Poll ONE granule (the last column, covered by the owner's last store instruction) until the row is
+            // on its way: 255 workgroups re-reading 48 KB each per failed poll would saturate the fabric.
+            if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
             for (int base = t; base < C; base += RS_NT * RS_FETCH) {
                 int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
 #pragma unroll
@@ -178,7 +226,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
             }
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
-        // ---- rank-1 update of the local rows and of the objective replica, :250-256 -------------------
+        RS_T(3);
+        // ---- objective replica first (:250-256 for row m): it names the NEXT entering column ---------------
         const double fobj = fac[rpw];
         const int skip = (w == owner) ? rl : -1;
         MinIdx best; best.v = -P.eps; best.i = INT_MAX;
@@ -190,14 +239,6 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
             *reinterpret_cast<double2*>(obj + j) = o;
             if (j < C - 1 && o.x < best.v) { best.v = o.x; best.i = j; }
             if (j + 1 < C - 1 && o.y < best.v) { best.v = o.y; best.i = j + 1; }
-            for (int i = 0; i < nloc; ++i) {
-                if (i == skip) continue;
-                const double f = fac[i];
-                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
-                prod = f * p.x; v.x = v.x - prod;
-                prod = f * p.y; v.y = v.y - prod;
-                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
-            }
         }
         if (w == 0 && t == 0) {
             P.basis[r] = q;                                                     // :110
@@ -205,9 +246,43 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         }
         qlast = q;
         ++iter;
-        best = block_min_idx<RS_NT>(best, s_v, s_i);                            // next ChooseEntering
-        q = best.i == INT_MAX ? -1 : best.i;
+        best = block_min_idx<RS_NT>(best, s_v, s_i);                            // next ChooseEntering, :205-220
+        const int qn = best.i == INT_MAX ? -1 : best.i;
+        RS_T(4);
+        // ---- lookahead: the ratios of the next pivot leave BEFORE the bulk of the update, so that their trip
+        //      overlaps it.  a' and rhs' are the values the update below is about to store (same mul, same sub).
+        if (qn >= 0 && iter < P.max_iter && k + 1 < P.chunk) {
+            if (t < nloc) {
+                double a, rhs;
+                if (t == skip) { a = prow[qn]; rhs = prow[C - 1]; }
+                else {
+                    const double f = fac[t];
+                    double prod = f * prow[qn]; a = tile[(size_t)t * ld + qn] - prod;
+                    prod = f * prow[C - 1]; rhs = tile[(size_t)t * ld + C - 1] - prod;
+                }
+                facn[t] = a;
+                rs_publish(P.xr + 2 * ((size_t)(par ^ 1) * P.mcap + row0 + t), a > P.eps ? rhs / a : __builtin_inf(), gen + 1u);
+            }
+            if (t == RS_NT - 1) facn[rpw] = obj[qn];
+        }
+        __syncthreads();                        // the lookahead read columns qn and C-1 before anyone rewrites them
+        RS_T(0);
+        // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + j);
+            for (int i = 0; i < nloc; ++i) {
+                if (i == skip) continue;
+                const double f = fac[i];
+                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                double prod = f * p.x; v.x = v.x - prod;
+                prod = f * p.y; v.y = v.y - prod;
+                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+            }
+        }
+        { double* sw = fac; fac = facn; facn = sw; }
+        q = qn;
         __syncthreads();
+        RS_T(5);
     }
 
     if (hung) {
@@ -235,7 +310,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
 static size_t resident_lds_bytes(int R, int C, int ld, int rpw)
 {
     const int m = R - 1;
-    return sizeof(double) * ((size_t)(rpw + 2) * ld + ((m + 1) & ~1) + (size_t)rpw + 2);
+    return sizeof(double) * ((size_t)(rpw + 2) * ld + ((m + 1) & ~1) + 2 * (size_t)((rpw + 2) & ~1) + 2);
 }
 
 // Picks the grid for a live shape; returns 0 when the tableau does not fit on chip.

@@ -245,6 +245,15 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
 }
 
 #ifdef LPX_STAMPS
+int lpx_debug_resident(lpx_tableau* t, unsigned long long* out, int n, int clear)
+{
+    if (!t->xp) return LPX_EINVAL;
+    LPX_HIP_TRY(hipMemcpy(out, t->xp + 4 * (size_t)t->ld, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (clear) LPX_HIP_TRY(hipMemset(t->xp + 4 * (size_t)t->ld, 0, sizeof(unsigned long long) * n));
+    return 0;
+}
+#endif
+#ifdef LPX_STAMPS
 extern "C++" { namespace lpx { hipError_t debug_copy_stamps(unsigned long long* out, int clear); } }
 int lpx_debug_hs(unsigned long long* out, int clear) { LPX_HIP_TRY(lpx::debug_copy_stamps(out, clear)); return 0; }
 int lpx_debug_ws(lpx_tableau* t, unsigned long long* out, int n, int clear)
@@ -342,7 +351,7 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
 {
     const int mcap = t->Rcap;
     if (!t->xr) {
-        const size_t rb = sizeof(unsigned long long) * 4 * (size_t)mcap, pb = sizeof(unsigned long long) * 4 * (size_t)t->ld;
+        const size_t rb = sizeof(unsigned long long) * 4 * (size_t)mcap, pb = sizeof(unsigned long long) * (4 * (size_t)t->ld + 64);   // + diagnostic stamps
         LPX_HIP_TRY(hipMalloc((void**)&t->xr, rb));
         LPX_HIP_TRY(hipMalloc((void**)&t->xp, pb));
         LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
