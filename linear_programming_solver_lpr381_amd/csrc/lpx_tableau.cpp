@@ -369,11 +369,22 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     int fired = 0, status = LPX_RUNNING;
     for (long long launches = 0; status == LPX_RUNNING; ++launches) {
         if (launches > (long long)o->max_iter + 4) { set_error("resident loop: launch budget exhausted while still running"); return LPX_ITER_LIMIT; }
+        if (o->profile) {
+            while (t->events.size() < 2) { hipEvent_t e; LPX_HIP_TRY(hipEventCreate(&e)); t->events.push_back(e); }
+            LPX_HIP_TRY(hipEventRecord(t->events[0], t->stream));
+        }
         LPX_HIP_TRY(launch_resident_primal(t->T, t->ld, t->R, t->C, grid, rpw, lds, mcap, t->basis, t->trace, t->trace_cap,
                                            t->st, t->xr, t->xp, t->xgen, o->eps, o->ratio_tol, o->max_iter, chunk, t->stream));
+        if (o->profile) LPX_HIP_TRY(hipEventRecord(t->events[1], t->stream));
         local.launches++;
         LPX_HIP_TRY(hipMemcpyAsync(t->hst, t->st, sizeof(DevState), hipMemcpyDeviceToHost, t->stream));
         LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        if (o->profile) {       // HIP events on the library stream around the persistent kernel: its duration
+            float ms = 0.f;
+            LPX_HIP_TRY(hipEventElapsedTime(&ms, t->events[0], t->events[1]));
+            local.update_ms_sum += ms;
+            local.update_launches++;
+        }
         if (t->hst->pad[1]) {
             // a bounded wait expired: some workgroup was not resident or died; rows in HBM are those of the last
             // completed launch.  Clear the exchange buffers so that no stale generation can ever match.

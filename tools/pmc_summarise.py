@@ -19,7 +19,7 @@ write = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for key in sorted(set(fetch) | set(write)):
     name, grid = key
-    if "lpx_update" not in name:
+    if "lpx_update" not in name and "lpx_resident" not in name:
         continue
     f = fetch.get(key, []); w = write.get(key, [])
     # drop early-exit launches (no traffic)
