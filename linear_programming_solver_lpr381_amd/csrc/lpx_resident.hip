@@ -23,6 +23,7 @@
 // Every wait is bounded (RS_SPIN_MAX polls); on expiry the workgroup raises the abort flag in the state
 // record and leaves without writing its rows back, and the host reports LPX_EDEVICE.
 #include "lpx_block.h"
+#include <cstdlib>
 
 namespace lpx {
 
@@ -41,6 +42,7 @@ struct ResParams {
     unsigned* xgen;                             // generation counter, survives launches
     double eps, tol;
     int max_iter, chunk;
+    int mute;                                   // diagnostic (LPX_RESIDENT_TEST_MUTE=1): the last workgroup plays dead
 };
 
 typedef unsigned long long u64;
@@ -68,15 +70,16 @@ __device__ __forceinline__ void rs_publish(u64* g, double v, unsigned gen)
 
 // Gathers count (<= RS_FETCH) granule pairs g[idx[u]] of generation `gen`; all loads of a round are in flight
 // together.  Returns false when the wait expired.
-__device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int count, unsigned gen, double* out)
+__device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int count, unsigned gen, double* out,
+                                          unsigned max_spin = RS_SPIN_MAX, unsigned* pend = nullptr)
 {
     static_assert(RS_FETCH == 4, "the load group below is written for four granule pairs");
-    unsigned pending = (1u << count) - 1u;
+    unsigned pending = pend ? *pend : (1u << count) - 1u;
     const u64* p0 = g + 2 * (size_t)idx[0];
     const u64* p1 = g + 2 * (size_t)idx[count > 1 ? 1 : 0];
     const u64* p2 = g + 2 * (size_t)idx[count > 2 ? 2 : 0];
     const u64* p3 = g + 2 * (size_t)idx[count > 3 ? 3 : 0];
-    for (unsigned spin = 0; spin < RS_SPIN_MAX && pending; ++spin) {
+    for (unsigned spin = 0; spin < max_spin && pending; ++spin) {
         rs_u4 w[RS_FETCH];
         asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                      "global_load_dwordx4 %1, %5, off sc1\n\t"
@@ -95,6 +98,7 @@ __device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int coun
         }
         if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
     }
+    if (pend) *pend = pending;
     return pending == 0;
 }
 
@@ -110,6 +114,24 @@ __device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
     return false;
 }
 
+// Block reductions of 1024-lane workgroups are slow when all 16 waves take part (four waves per SIMD take turns
+// through the same DPP chain, then all of them reduce the partials again: ~1 us).  The small vectors of this
+// kernel (objective row, ratios) are reduced by waves 0-3 only -- one per SIMD -- and the other waves just wait.
+static constexpr int RS_RT = 256;               // lanes that hold candidates
+__device__ __forceinline__ MinIdx first4_min_idx(MinIdx x, double* s_v, int* s_i)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 4) {
+        x = wave_min_idx(x);
+        if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
+    }
+    __syncthreads();
+    MinIdx y; y.v = s_v[0]; y.i = s_i[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { MinIdx z; z.v = s_v[k]; z.i = s_i[k]; y = mi_pick(y, z); }
+    return y;
+}
+
 struct LdsRatio {
     const double* v;
     __device__ __forceinline__ double den(int i) const { return v[i]; }
@@ -121,12 +143,13 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
 {
     extern __shared__ __align__(16) double rs_lds[];
     __shared__ double s_v[RS_NT / 64];
-    __shared__ int s_i[RS_NT / 64];
+    __shared__ int s_i[RS_NT / 64];             // [0..3] partial argmins, [4..7] partial band counts
     __shared__ int s_out;
 
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, w = blockIdx.x;
+    if (P.mute && w == (int)gridDim.x - 1) return;
     const int ld = P.ld, C = P.C, m = P.R - 1, rpw = P.rpw;
     const int row0 = w * rpw;
     const int nloc = max(0, min(rpw, m - row0));
@@ -190,13 +213,33 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
         RS_T(1);
-        // the hysteresis scan of :234-241: one wave of every workgroup runs it on the same data
-        if ((t >> 6) == 0) {
-            const int win = wave_hysteresis_argmin(m, P.tol, LdsRatio{ratios});
-            if (t == 0) s_out = win;
+        // The hysteresis scan of :234-241, identical in every workgroup.  Fast path (lpx_block.h,
+        // wave_hysteresis_argmin): with rmin the smallest ratio and i* its first row, if no OTHER row j has
+        // fl(r_j - tol) <= rmin the sequential scan ends at i* whatever it accepted on the way.  Ties and
+        // near-ties (the degenerate vertices of 0/1 programs) take the exact scan on wave 0.
+        MinIdx lm; lm.v = __builtin_inf(); lm.i = INT_MAX;
+        if (t < RS_RT)
+            for (int i = t; i < m; i += RS_RT) { const double v = ratios[i]; if (v < lm.v) { lm.v = v; lm.i = i; } }
+        lm = first4_min_idx(lm, s_v, s_i);
+        if (lm.i == INT_MAX) { r = -1; }
+        else {
+            if (t < RS_RT) {
+                int inband = 0;
+                for (int i = t; i < m; i += RS_RT) inband += ((ratios[i] - P.tol) <= lm.v) ? 1 : 0;
+                const int wsum = __popcll(__ballot(inband == 1)) + 2 * __popcll(__ballot(inband >= 2));
+                if ((t & 63) == 0) s_i[4 + (t >> 6)] = wsum;
+            }
+            __syncthreads();
+            if (s_i[4] + s_i[5] + s_i[6] + s_i[7] == 1) r = lm.i;
+            else {
+                if ((t >> 6) == 0) {
+                    const int win = wave_hysteresis_argmin(m, P.tol, LdsRatio{ratios});
+                    if (t == 0) s_out = win;
+                }
+                __syncthreads();
+                r = s_out;
+            }
         }
-        __syncthreads();
-        r = s_out;
         if (r < 0) { status = LPX_UNBOUNDED; break; }                          // :102-106
         RS_T(2);
         // ---- exchange 2: the normalised pivot row, :247-249 ----------------------------------------
@@ -215,12 +258,21 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         } else {
             // Poll ONE granule (the last column, covered by the owner's last store instruction) until the row is
             // on its way: 255 workgroups re-reading 48 KB each per failed poll would saturate the fabric.
-            if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
+            // The owner needs 0.5-1 us to divide and store the row: sleep through that, then try the
+            // whole gather ONCE -- when the row is already visible this saves the canary's round trip.
+            __builtin_amdgcn_s_sleep(15);
+            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);   // measured best: 20 (C = 769) ... 35 (C = 3073) x 64 cycles
+            bool first = true;
             for (int base = t; base < C; base += RS_NT * RS_FETCH) {
                 int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
 #pragma unroll
                 for (int u = 0; u < RS_FETCH; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < C) cnt = u + 1; }
-                if (!rs_gather(xp, idx, cnt, gen, val)) fail = 1;
+                unsigned pend = (1u << cnt) - 1u;
+                if (first && !rs_gather(xp, idx, cnt, gen, val, 1u, &pend)) {
+                    if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
+                }
+                first = false;
+                if (pend && !rs_gather(xp, idx, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
 #pragma unroll
                 for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) prow[idx[u]] = val[u];
             }
@@ -231,14 +283,16 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         const double fobj = fac[rpw];
         const int skip = (w == owner) ? rl : -1;
         MinIdx best; best.v = -P.eps; best.i = INT_MAX;
-        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
-            const double2 p = *reinterpret_cast<const double2*>(prow + j);
-            double2 o = *reinterpret_cast<double2*>(obj + j);
-            double prod = fobj * p.x; o.x = o.x - prod;
-            prod = fobj * p.y; o.y = o.y - prod;
-            *reinterpret_cast<double2*>(obj + j) = o;
-            if (j < C - 1 && o.x < best.v) { best.v = o.x; best.i = j; }
-            if (j + 1 < C - 1 && o.y < best.v) { best.v = o.y; best.i = j + 1; }
+        if (t < RS_RT) {
+            for (int j = 2 * t; j < ld; j += 2 * RS_RT) {
+                const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                double2 o = *reinterpret_cast<double2*>(obj + j);
+                double prod = fobj * p.x; o.x = o.x - prod;
+                prod = fobj * p.y; o.y = o.y - prod;
+                *reinterpret_cast<double2*>(obj + j) = o;
+                if (j < C - 1 && o.x < best.v) { best.v = o.x; best.i = j; }
+                if (j + 1 < C - 1 && o.y < best.v) { best.v = o.y; best.i = j + 1; }
+            }
         }
         if (w == 0 && t == 0) {
             P.basis[r] = q;                                                     // :110
@@ -246,7 +300,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         }
         qlast = q;
         ++iter;
-        best = block_min_idx<RS_NT>(best, s_v, s_i);                            // next ChooseEntering, :205-220
+        best = first4_min_idx(best, s_v, s_i);                                  // next ChooseEntering, :205-220
         const int qn = best.i == INT_MAX ? -1 : best.i;
         RS_T(4);
         // ---- lookahead: the ratios of the next pivot leave BEFORE the bulk of the update, so that their trip
@@ -351,6 +405,8 @@ hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int
     p.T = T; p.ld = ld; p.R = R; p.C = C; p.rpw = rpw; p.mcap = mcap;
     p.basis = basis; p.trace = trace; p.trace_cap = trace_cap; p.st = st;
     p.xr = xr; p.xp = xp; p.xgen = xgen; p.eps = eps; p.tol = tol; p.max_iter = max_iter; p.chunk = chunk;
+    static const bool mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e && e[0] == '1'; }();
+    p.mute = mute ? 1 : 0;
     hipLaunchKernelGGL(lpx_resident_primal, dim3(grid), dim3(RS_NT), lds, s, p);
     return hipGetLastError();
 }

@@ -42,7 +42,11 @@ struct lpx_tableau {
     std::vector<hipEvent_t> events;
     // resident primal loop: exchange buffers (tagged granules) and the generation counter
     unsigned long long* xr = nullptr; unsigned long long* xp = nullptr; unsigned* xgen = nullptr;
+    int32_t* xbasis = nullptr;      // basis as it was before the first resident launch of a run
+    bool resident_off = false;      // a resident launch could not get its workgroups co-resident: stay on the streaming path
 };
+
+static constexpr int LPX_RESIDENT_RETRY = -1000;     // internal: first resident launch timed out, state untouched
 
 static void drop_graph(lpx_tableau* t)
 {
@@ -168,7 +172,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws); hipFree(t->part_v); hipFree(t->part_i); hipFree(t->us);
     hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf); hipFree(t->shape);
-    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen);
+    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis);
     if (t->shape_h) hipHostFree(t->shape_h);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
     if (t->hst) hipHostFree(t->hst);
@@ -355,6 +359,7 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
         LPX_HIP_TRY(hipMalloc((void**)&t->xr, rb));
         LPX_HIP_TRY(hipMalloc((void**)&t->xp, pb));
         LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
+        LPX_HIP_TRY(hipMalloc((void**)&t->xbasis, sizeof(int32_t) * (size_t)mcap));
         LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, rb, t->stream));
         LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, pb, t->stream));
         LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
@@ -363,6 +368,7 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
     *t->hst = init;
     LPX_HIP_TRY(hipMemcpyAsync(t->st, t->hst, sizeof(DevState), hipMemcpyHostToDevice, t->stream));
+    LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, t->stream));
     const int chunk = cb ? (o->batch > 0 ? o->batch : 256) : (1 << 30);
     lpx_stats local; std::memset(&local, 0, sizeof(local));
     const double t0 = now_ms();
@@ -392,6 +398,13 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
             hipMemsetAsync(t->xp, 0, sizeof(unsigned long long) * 4 * (size_t)t->ld, t->stream);
             hipStreamSynchronize(t->stream);
             set_error("resident loop: an exchange wait expired (workgroups not co-resident?)");
+            if (launches == 0) {
+                // Nothing was written back (a workgroup that cannot finish keeps every other one from finishing):
+                // the tableau is the one the run started from; put the basis back and let the caller stream.
+                LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
+                t->resident_off = true;
+                return LPX_RESIDENT_RETRY;
+            }
             return LPX_EDEVICE;
         }
         status = t->hst->status;
@@ -562,7 +575,11 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
     static const bool res_env = [] { const char* e = std::getenv("LPX_RESIDENT"); return !(e && e[0] == '0'); }();
     if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
         int grid = 0, rpw = 0; size_t lds = 0;
-        if (resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds)) return run_resident(t, o, cb, user, st, grid, rpw, lds);
+        if (!t->resident_off && resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds)) {
+            const int rc = run_resident(t, o, cb, user, st, grid, rpw, lds);
+            if (rc != LPX_RESIDENT_RETRY) return rc;
+            if (o->resident > 0) return LPX_EDEVICE;        // required, and it could not run
+        } else
         if (o->resident > 0) { set_error("lpx_primal_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
     SelParams p = base_params(t, o, MODE_PRIMAL);

@@ -114,3 +114,40 @@ def test_resident_required_but_too_large(gpu):
     with gpu.DeviceTableau.from_host(T) as dt:
         with pytest.raises(gpu.LpxError, match="does not fit"):
             dt.primal_run(resident=1, max_iter=1)
+
+
+def test_resident_falls_back_to_streaming_when_a_workgroup_is_missing(oracle):
+    """LPX_RESIDENT_TEST_MUTE=1 makes one workgroup play dead: every exchange wait expires (bounded spins, ~2 s),
+    nothing is written back, and an automatic run streams the same LP to the same bits; resident=1 reports it."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, time
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        from oracle import oracle as O
+        c, A, b = synth.dense_lp(40, 60, seed=2)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref = O.primal_tableau(Tr, br)
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            dt.snapshot()
+            try:
+                dt.primal_run(resident=1)
+                raise SystemExit("resident=1 should have failed")
+            except L.LpxError as e:
+                assert "exchange wait expired" in str(e), e
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            t0 = time.time()
+            status, st = dt.primal_run()
+            Tg, bg = dt.download()
+            assert status == st_ref and st["launches"] > 2
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+            assert dt.trace().tolist() == tr_ref.tolist()
+            t1 = time.time()
+            dt.upload(T, basis); dt.primal_run()          # the handle stays on the streaming path: no second wait
+            assert time.time() - t1 < 0.5 * (t1 - t0) + 0.5
+        print("OK")
+    ''')
+    env = dict(os.environ, LPX_RESIDENT_TEST_MUTE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
