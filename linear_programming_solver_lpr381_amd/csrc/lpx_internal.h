@@ -101,6 +101,7 @@ struct LoopCtx {
     std::function<int(hipStream_t)> prologue;                               // once, before the loop
     int launches_per_iter = 2;
     bool profile_maps = true;          // pivot k of a batch == k-th enqueued iteration
+    int start_iter = 0;                // pivots already done on this tableau by another path (resident loop hand-over)
 };
 int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
                     lpx_pivot_cb cb, void* user, lpx_stats* stats);

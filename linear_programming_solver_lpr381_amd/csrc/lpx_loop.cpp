@@ -73,12 +73,13 @@ int LoopRun::begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o
                    lpx_pivot_cb cb, void* user)
 {
     c_ = c; o_ = *o; budget_ = budget; cb_ = cb; user_ = user;
-    enq_ = 0; fired_ = 0; status_ = LPX_RUNNING; init_phase_ = init.phase;
+    enq_ = 0; fired_ = c.start_iter; status_ = LPX_RUNNING; init_phase_ = init.phase;
     std::memset(&local_, 0, sizeof(local_));
     batch_ = o_.batch > 0 ? o_.batch : 64;
     if (o_.profile && batch_ > 256) batch_ = 256;
     graph_ = o_.use_graph && !o_.profile;
     *c_.hst = init;                                 // pinned staging: safe for the async copy below
+    c_.hst->iter = c.start_iter; c_.hst->primal_count = (init.phase == 2) ? c.start_iter : 0;
     LPX_HIP_TRY(hipMemcpyAsync(c_.st, c_.hst, sizeof(DevState), hipMemcpyHostToDevice, c_.stream));
     LPX_HIP_TRY(hipStreamSynchronize(c_.stream));
     if (o_.profile) {

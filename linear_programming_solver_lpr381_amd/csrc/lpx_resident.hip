@@ -42,7 +42,7 @@ struct ResParams {
     unsigned* xgen;                             // generation counter, survives launches
     double eps, tol;
     int max_iter, chunk;
-    int mute;                                   // diagnostic (LPX_RESIDENT_TEST_MUTE=1): the last workgroup plays dead
+    int mute;                                   // diagnostic (LPX_RESIDENT_TEST_MUTE=1|2): the last workgroup plays dead
 };
 
 typedef unsigned long long u64;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, w = blockIdx.x;
-    if (P.mute && w == (int)gridDim.x - 1) return;
+    if ((P.mute == 1 || (P.mute == 2 && st->iter > 0)) && w == (int)gridDim.x - 1) return;   // 2: from the second launch on
     const int ld = P.ld, C = P.C, m = P.R - 1, rpw = P.rpw;
     const int row0 = w * rpw;
     const int nloc = max(0, min(rpw, m - row0));
@@ -405,8 +405,8 @@ hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int
     p.T = T; p.ld = ld; p.R = R; p.C = C; p.rpw = rpw; p.mcap = mcap;
     p.basis = basis; p.trace = trace; p.trace_cap = trace_cap; p.st = st;
     p.xr = xr; p.xp = xp; p.xgen = xgen; p.eps = eps; p.tol = tol; p.max_iter = max_iter; p.chunk = chunk;
-    static const bool mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e && e[0] == '1'; }();
-    p.mute = mute ? 1 : 0;
+    static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
+    p.mute = mute;
     hipLaunchKernelGGL(lpx_resident_primal, dim3(grid), dim3(RS_NT), lds, s, p);
     return hipGetLastError();
 }

@@ -322,10 +322,11 @@ void make_ctx(lpx_tableau* t, const SelParams& p, LoopCtx& c, DevState& init)
 }
 
 int run_loop(lpx_tableau* t, SelParams p, const lpx_run_opts* o, long long budget,
-             lpx_pivot_cb cb, void* user, lpx_stats* stats)
+             lpx_pivot_cb cb, void* user, lpx_stats* stats, int start_iter = 0)
 {
     LoopCtx c; DevState init;
     make_ctx(t, p, c, init);
+    c.start_iter = start_iter;
     return run_device_loop(c, init, o, budget, cb, user, stats);
 }
 
@@ -351,7 +352,7 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
 // Resident primal loop: one launch runs up to `chunk` pivots with the tableau in LDS; the host only polls the
 // 64-byte state record between launches (and fires the pivot callbacks from the trace).
 int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* stats,
-                 int grid, int rpw, size_t lds)
+                 int grid, int rpw, size_t lds, int* resume_iter)
 {
     const int mcap = t->Rcap;
     if (!t->xr) {
@@ -368,13 +369,14 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
     *t->hst = init;
     LPX_HIP_TRY(hipMemcpyAsync(t->st, t->hst, sizeof(DevState), hipMemcpyHostToDevice, t->stream));
-    LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, t->stream));
     const int chunk = cb ? (o->batch > 0 ? o->batch : 256) : (1 << 30);
     lpx_stats local; std::memset(&local, 0, sizeof(local));
     const double t0 = now_ms();
     int fired = 0, status = LPX_RUNNING;
     for (long long launches = 0; status == LPX_RUNNING; ++launches) {
         if (launches > (long long)o->max_iter + 4) { set_error("resident loop: launch budget exhausted while still running"); return LPX_ITER_LIMIT; }
+        // basis as of the start of this launch: a launch that cannot finish writes nothing else back
+        LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, t->stream));
         if (o->profile) {
             while (t->events.size() < 2) { hipEvent_t e; LPX_HIP_TRY(hipEventCreate(&e)); t->events.push_back(e); }
             LPX_HIP_TRY(hipEventRecord(t->events[0], t->stream));
@@ -398,14 +400,13 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
             hipMemsetAsync(t->xp, 0, sizeof(unsigned long long) * 4 * (size_t)t->ld, t->stream);
             hipStreamSynchronize(t->stream);
             set_error("resident loop: an exchange wait expired (workgroups not co-resident?)");
-            if (launches == 0) {
-                // Nothing was written back (a workgroup that cannot finish keeps every other one from finishing):
-                // the tableau is the one the run started from; put the basis back and let the caller stream.
-                LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
-                t->resident_off = true;
-                return LPX_RESIDENT_RETRY;
-            }
-            return LPX_EDEVICE;
+            // Nothing of this launch was written back (a workgroup that cannot finish keeps every other one from
+            // finishing): the tableau is that of the previous launch; put its basis back and hand over to the
+            // streaming kernels, which continue from pivot `resume_iter`.
+            LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
+            t->resident_off = true;
+            *resume_iter = fired;
+            return LPX_RESIDENT_RETRY;
         }
         status = t->hst->status;
         const int done = t->hst->iter;
@@ -573,17 +574,18 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
     if (t->R < 2) { set_error("lpx_primal_run: tableau needs at least one constraint row"); return LPX_EINVAL; }
     // Tableau small enough to live on chip: persistent workgroups, no per-pivot HBM traffic (lpx_resident.hip).
     static const bool res_env = [] { const char* e = std::getenv("LPX_RESIDENT"); return !(e && e[0] == '0'); }();
+    int resume = 0;
     if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
         int grid = 0, rpw = 0; size_t lds = 0;
         if (!t->resident_off && resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds)) {
-            const int rc = run_resident(t, o, cb, user, st, grid, rpw, lds);
+            const int rc = run_resident(t, o, cb, user, st, grid, rpw, lds, &resume);
             if (rc != LPX_RESIDENT_RETRY) return rc;
             if (o->resident > 0) return LPX_EDEVICE;        // required, and it could not run
         } else
         if (o->resident > 0) { set_error("lpx_primal_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
     SelParams p = base_params(t, o, MODE_PRIMAL);
-    return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st);
+    return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st, resume);
 }
 
 int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* st)

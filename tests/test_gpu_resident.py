@@ -151,3 +151,29 @@ def test_resident_falls_back_to_streaming_when_a_workgroup_is_missing(oracle):
     env = dict(os.environ, LPX_RESIDENT_TEST_MUTE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    # LPX_RESIDENT_TEST_MUTE=2: the workgroup dies from the SECOND launch on -- the streaming kernels take over in
+    # mid-solve (pivot 32 of a chunked run) and the callbacks, trace and tableau still come out whole.
+    code2 = textwrap.dedent('''
+        import numpy as np
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        from oracle import oracle as O
+        c, A, b = synth.dense_lp(96, 150, seed=21)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref = O.primal_tableau(Tr, br)
+        assert len(tr_ref) > 40
+        ev = []
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, st = dt.primal_run(resident=0, batch=16 * 2, cb=lambda it, r, q: ev.append((it, r, q)))
+            Tg, bg = dt.download()
+            assert status == st_ref and st["pivots"] == len(tr_ref)
+            assert [e[0] for e in ev] == list(range(1, len(tr_ref) + 1))
+            assert [(e[1], e[2]) for e in ev] == [tuple(x) for x in tr_ref.tolist()]
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+            assert dt.trace().tolist() == tr_ref.tolist()
+        print("OK")
+    ''')
+    env["LPX_RESIDENT_TEST_MUTE"] = "2"
+    r = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
