@@ -73,6 +73,21 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
                              int32_t* basis, hipStream_t s);
 hipError_t kernels_init();          // one-time function attributes
+// resident group loop (lpx_resident_group.hip): one entry per node of a launch
+struct ResNode {
+    double* T; int ld, R, C;
+    int32_t* basis; int32_t* trace; int trace_cap;
+    DevState* st;
+    unsigned long long* xr;  // [2][mcap][2][2]  (a, rhs) granule pairs per row
+    unsigned long long* xp;  // [2][ld+8][2]     pivot row granules, then the header {q}
+    unsigned* xgen;
+    int mcap, dual;
+    double eps, tol_fdf, tol_dual, tol_primal;
+    int max_iter, fdf_guard, cleanup;
+};
+size_t resident_group_lds(int R, int C, int ld, int grid);
+hipError_t resident_group_init();
+hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s);
 // resident primal loop (lpx_resident.hip)
 hipError_t resident_init();
 int resident_plan(int R, int C, int ld, int* grid, int* rpw, size_t* lds);      // 0 = does not fit on chip

@@ -27,7 +27,8 @@ int ensure_device()
         g_device = 0;
         LPX_HIP_TRY(hipSetDevice(0));
     }
-    std::call_once(g_init_once, [] { g_init_err = kernels_init(); if (g_init_err == hipSuccess) g_init_err = resident_init(); });
+    std::call_once(g_init_once, [] { g_init_err = kernels_init(); if (g_init_err == hipSuccess) g_init_err = resident_init();
+                                     if (g_init_err == hipSuccess) g_init_err = resident_group_init(); });
     if (g_init_err != hipSuccess) {
         set_error(std::string("kernel attribute setup failed: ") + hipGetErrorString(g_init_err));
         return LPX_EDEVICE;
@@ -79,7 +80,7 @@ int LoopRun::begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o
     if (o_.profile && batch_ > 256) batch_ = 256;
     graph_ = o_.use_graph && !o_.profile;
     *c_.hst = init;                                 // pinned staging: safe for the async copy below
-    c_.hst->iter = c.start_iter; c_.hst->primal_count = (init.phase == 2) ? c.start_iter : 0;
+    if (c.start_iter > 0) { c_.hst->iter = c.start_iter; c_.hst->primal_count = (init.phase == 2) ? c.start_iter : 0; }
     LPX_HIP_TRY(hipMemcpyAsync(c_.st, c_.hst, sizeof(DevState), hipMemcpyHostToDevice, c_.stream));
     LPX_HIP_TRY(hipStreamSynchronize(c_.stream));
     if (o_.profile) {

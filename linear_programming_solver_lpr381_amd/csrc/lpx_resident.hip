@@ -22,14 +22,10 @@
 // run at most one exchange ahead of the slowest one (it needs that one's ratio to get the next pivot row).
 // Every wait is bounded (RS_SPIN_MAX polls); on expiry the workgroup raises the abort flag in the state
 // record and leaves without writing its rows back, and the host reports LPX_EDEVICE.
-#include "lpx_block.h"
+#include "lpx_resident.h"
 #include <cstdlib>
 
 namespace lpx {
-
-static constexpr int RS_NT = 1024;
-static constexpr unsigned RS_SPIN_MAX = 1u << 21;
-static constexpr int RS_FETCH = 4;              // granule pairs in flight per lane while gathering
 
 struct ResParams {
     double* T; int ld; int R; int C;            // live shape
@@ -45,8 +41,6 @@ struct ResParams {
     int mute;                                   // diagnostic (LPX_RESIDENT_TEST_MUTE=1|2): the last workgroup plays dead
 };
 
-typedef unsigned long long u64;
-
 #ifdef LPX_STAMPS
 #define RS_T0 unsigned long long rs_prev_ = __builtin_amdgcn_s_memtime();
 #define RS_T(slot) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1 ? 1 : 0)) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); P.xp[4 * (size_t)P.ld + (slot)] += n_ - rs_prev_; rs_prev_ = n_; } } while (0)
@@ -54,90 +48,6 @@ typedef unsigned long long u64;
 #define RS_T0
 #define RS_T(slot) do {} while (0)
 #endif
-
-typedef unsigned rs_u4 __attribute__((ext_vector_type(4)));
-
-// One double = one 16-byte granule pair {lo32, tag, hi32, tag}: a single write-through dwordx4 store, a single
-// dwordx4 sc1 load.  Each 8-byte half validates itself, so it does not matter whether the fabric keeps the 16
-// bytes together.
-__device__ __forceinline__ void rs_publish(u64* g, double v, unsigned gen)
-{
-    const u64 bits = (u64)__double_as_longlong(v);
-    rs_u4 w;
-    w.x = (unsigned)bits; w.y = gen; w.z = (unsigned)(bits >> 32); w.w = gen;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(g), "v"(w) : "memory");
-}
-
-// Gathers count (<= RS_FETCH) granule pairs g[idx[u]] of generation `gen`; all loads of a round are in flight
-// together.  Returns false when the wait expired.
-__device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int count, unsigned gen, double* out,
-                                          unsigned max_spin = RS_SPIN_MAX, unsigned* pend = nullptr)
-{
-    static_assert(RS_FETCH == 4, "the load group below is written for four granule pairs");
-    unsigned pending = pend ? *pend : (1u << count) - 1u;
-    const u64* p0 = g + 2 * (size_t)idx[0];
-    const u64* p1 = g + 2 * (size_t)idx[count > 1 ? 1 : 0];
-    const u64* p2 = g + 2 * (size_t)idx[count > 2 ? 2 : 0];
-    const u64* p3 = g + 2 * (size_t)idx[count > 3 ? 3 : 0];
-    for (unsigned spin = 0; spin < max_spin && pending; ++spin) {
-        rs_u4 w[RS_FETCH];
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                     "global_load_dwordx4 %1, %5, off sc1\n\t"
-                     "global_load_dwordx4 %2, %6, off sc1\n\t"
-                     "global_load_dwordx4 %3, %7, off sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-                     : "memory");
-#pragma unroll
-        for (int u = 0; u < RS_FETCH; ++u) {
-            if (((pending >> u) & 1u) && w[u].y == gen && w[u].w == gen) {
-                out[u] = __longlong_as_double((long long)(((u64)w[u].z << 32) | (u64)w[u].x));
-                pending &= ~(1u << u);
-            }
-        }
-        if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
-    }
-    if (pend) *pend = pending;
-    return pending == 0;
-}
-
-// Waits until one granule pair carries generation `gen` (same address in every lane: one request per wave).
-__device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
-{
-    for (unsigned spin = 0; spin < RS_SPIN_MAX; ++spin) {
-        rs_u4 w;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(g) : "memory");
-        if (w.y == gen && w.w == gen) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
-// Block reductions of 1024-lane workgroups are slow when all 16 waves take part (four waves per SIMD take turns
-// through the same DPP chain, then all of them reduce the partials again: ~1 us).  The small vectors of this
-// kernel (objective row, ratios) are reduced by waves 0-3 only -- one per SIMD -- and the other waves just wait.
-static constexpr int RS_RT = 256;               // lanes that hold candidates
-__device__ __forceinline__ MinIdx first4_min_idx(MinIdx x, double* s_v, int* s_i)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < 4) {
-        x = wave_min_idx(x);
-        if (lane == 0) { s_v[wave] = x.v; s_i[wave] = x.i; }
-    }
-    __syncthreads();
-    MinIdx y; y.v = s_v[0]; y.i = s_i[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) { MinIdx z; z.v = s_v[k]; z.i = s_i[k]; y = mi_pick(y, z); }
-    return y;
-}
-
-struct LdsRatio {
-    const double* v;
-    __device__ __forceinline__ double den(int i) const { return v[i]; }
-    __device__ __forceinline__ double num(int) const { return 0.0; }
-    __device__ __forceinline__ double value(double a, double) const { return a; }
-};
 
 __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
 {

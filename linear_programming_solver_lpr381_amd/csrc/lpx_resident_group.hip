@@ -1,0 +1,322 @@
+// lpx_resident_group.hip -- several node LPs at once, each resident in the LDS of its own slice of the chip.
+//
+// Branch-and-bound nodes of config 4 are 8 MB tableaux: one fills a quarter of the chip's LDS.  This kernel is the
+// resident loop of lpx_resident.hip generalised in two directions:
+//   * blockIdx.y selects the node: `gridDim.x` workgroups (one per CU) own the rows of one tableau, and gridDim.y
+//     such groups run side by side -- 4 nodes x 64 CUs instead of 32 nodes taking turns through HBM;
+//   * the full state machine of the dual path (lpx_select_body in lpx_kernels.hip): ForceDualFeasibility
+//     (Models/DualSimplex.cs:195-228), the dual loop (:36-113) and the repaired mode's primal clean-up, with the
+//     primal loop (Models/PrimalSimplex.cs:92-124) as the special case "phase 2 from the start".
+// Exchange 1 carries TWO values per row: the ratio rhs_i / T[i, q] for the entering column the primal-like phases
+// will use (every workgroup knows q from its objective replica; +inf when ineligible), and rhs_i for the dual loop's leaving row
+// (most negative RHS, first index).  In the dual loop the entering column is chosen by the OWNER of row r -- it has
+// the row and the objective replica, so the column ratio scan of :79-91 is local -- and travels as a header
+// granule behind the normalised row.  Control state (phase, counters) is replicated: every workgroup of a group
+// sees the same gathered data and takes the same decisions.
+// Arithmetic per element is that of lpx_update / lpx_select, so results are bit-identical to the streaming kernels.
+#include "lpx_resident.h"
+#include <cstdlib>
+
+namespace lpx {
+
+struct ResGroupParams { const ResNode* nodes; int chunk; };
+
+__device__ __forceinline__ int first4_first_min_below(const double* v, int L, double eps, double* s_v, int* s_i)
+{
+    MinIdx m; m.v = -eps; m.i = INT_MAX;
+    if (threadIdx.x < RS_RT)
+        for (int j = threadIdx.x; j < L; j += RS_RT) { const double x = v[j]; if (x < m.v) { m.v = x; m.i = j; } }
+    m = first4_min_idx(m, s_v, s_i);
+    __syncthreads();                                // s_v / s_i may be reused at once
+    return m.i == INT_MAX ? -1 : m.i;
+}
+
+__global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP)
+{
+    extern __shared__ __align__(16) double rs_lds[];
+    __shared__ double s_v[RS_NT / 64];
+    __shared__ int s_i[RS_NT / 64];
+    __shared__ int s_out;
+
+    const ResNode P = GP.nodes[blockIdx.y];
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
+    const int ld = P.ld, C = P.C, m = P.R - 1, rhsc = C - 1;
+    const int rpw = (m + G - 1) / G;
+    const int row0 = w * rpw;
+    const int nloc = max(0, min(rpw, m - row0));
+    const int mp = (m + 1) & ~1;
+    double* tile = rs_lds;                      // [rpw][ld]
+    double* obj = tile + (size_t)rpw * ld;      // [ld]
+    double* prow = obj + ld;                    // [ld]
+    double* colA = prow + ld;                   // [m]  gathered ratios rhs_i / a_i (+inf when a_i <= eps)
+    double* colB = colA + mp;                   // [m]  gathered rhs_i
+    double* fac = colB + mp;                    // [rpw+1]
+
+    for (int i = 0; i < nloc; ++i) {
+        const double* src = P.T + (size_t)(row0 + i) * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = *reinterpret_cast<const double2*>(src + j);
+    }
+    {
+        const double* src = P.T + (size_t)m * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            *reinterpret_cast<double2*>(obj + j) = *reinterpret_cast<const double2*>(src + j);
+            *reinterpret_cast<double2*>(prow + j) = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
+    int phase = P.dual ? st->phase : 2;
+    int fdf_count = st->fdf_count, dual_iter = st->dual_iter, primal_count = st->primal_count, iter = st->iter;
+    unsigned gen = *P.xgen;
+    int status = LPX_RUNNING;
+    bool hung = false;
+    int r = -1, qlast = -1;
+    // entering column the primal-like phases would take now (ChooseEntering, Models/PrimalSimplex.cs:205-220)
+    int qc = (phase != 1) ? first4_first_min_below(obj, rhsc, P.eps, s_v, s_i) : -1;
+    bool publish_now = GP.chunk > 0;            // rows' (a, rhs) for the first round of this launch
+
+    for (int k = 0; k < GP.chunk; ++k) {
+        if (publish_now) {
+            if (t < nloc) {
+                u64* g = P.xr + 4 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t);
+                const double rhs0 = tile[(size_t)t * ld + rhsc];
+                const double a0 = qc >= 0 ? tile[(size_t)t * ld + qc] : 0.0;
+                rs_publish(g, a0 > P.eps ? rhs0 / a0 : __builtin_inf(), gen + 1u);        // ratio of :229-233
+                rs_publish(g + 2, rhs0, gen + 1u);
+            }
+            publish_now = false;
+        }
+        ++gen;
+        const int par = (int)(gen & 1u);
+        // ---- exchange 1: (a_i, rhs_i) of every row ------------------------------------------------------------
+        int fail = 0;
+        for (int base = t; base < m; base += RS_NT * 2) {
+            int idx[RS_FETCH]; double val[RS_FETCH];
+            const int i0 = base, i1 = base + RS_NT;
+            idx[0] = 2 * i0; idx[1] = 2 * i0 + 1; idx[2] = 2 * (i1 < m ? i1 : i0); idx[3] = idx[2] + 1;
+            if (!rs_gather(P.xr + 4 * (size_t)par * P.mcap, idx, i1 < m ? 4 : 2, gen, val)) fail = 1;
+            colA[i0] = val[0]; colB[i0] = val[1];
+            if (i1 < m) { colA[i1] = val[2]; colB[i1] = val[3]; }
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+
+        // ---- the decision of lpx_select_body, replicated ------------------------------------------------------------
+        int q = -1, final_status = LPX_RUNNING;
+        bool republish = false;
+        r = -1;
+        for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0 && !republish; ++hop) {
+            if (phase == 0) {                                                   // ForceDualFeasibility, :195-228
+                if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
+                q = qc;
+                if (q < 0) { phase = 1; continue; }
+                r = rs_hysteresis(m, P.tol_fdf, colA, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; phase = 1; continue; }
+            } else if (phase == 1) {                                            // dual loop, :36-113
+                if (dual_iter >= P.max_iter) { final_status = LPX_ITER_LIMIT; break; }
+                r = first4_first_min_below(colB, m, P.eps, s_v, s_i);           // most negative RHS, first index (:45-55)
+                if (r < 0) {
+                    if (P.cleanup) {
+                        const int qe = first4_first_min_below(obj, rhsc, P.eps, s_v, s_i);
+                        if (qe >= 0) { phase = 2; qc = qe; republish = true; break; }   // the rows' a_i for qe are not out yet
+                    }
+                    final_status = LPX_OPTIMAL; break;
+                }
+                q = -2;                                                         // chosen by the owner of row r below
+            } else {                                                            // primal loop, PrimalSimplex.cs:92-124
+                if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
+                q = qc;
+                if (q < 0) { final_status = LPX_OPTIMAL; break; }
+                r = rs_hysteresis(m, P.tol_primal, colA, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
+            }
+        }
+        if (republish) { publish_now = true; continue; }                        // one exchange round without a pivot
+        if (final_status != LPX_RUNNING || r < 0) { status = (final_status == LPX_RUNNING) ? LPX_OPTIMAL : final_status; break; }
+
+        // ---- exchange 2: the owner normalises row r (and, in the dual loop, chooses the entering column) ---------
+        const int owner = r / rpw, rl = r - owner * rpw;
+        u64* xp = P.xp + 2 * (size_t)par * (ld + 8);
+        if (w == owner) {
+            double* prw = tile + (size_t)rl * ld;
+            if (phase == 1) {                                                   // entering column of the dual loop, :79-91
+                if ((t >> 6) == 0) {
+                    const int win = wave_hysteresis_argmin(rhsc, P.tol_dual, DualColRatio{prw, obj, P.eps});
+                    if (t == 0) s_out = win;
+                }
+                __syncthreads();
+                q = s_out;
+            }
+            if (q >= 0) {
+                const double piv = prw[q];
+                __syncthreads();
+                for (int j = t; j < C; j += RS_NT) {
+                    const double p = prw[j] / piv;
+                    rs_publish(xp + 2 * (size_t)j, p, gen);
+                    prw[j] = p;
+                    prow[j] = p;
+                }
+            }
+            if (phase == 1) {
+                __syncthreads();
+                if (t == 0) rs_publish(xp + 2 * (size_t)ld, (double)q, gen);    // header {q} behind the row
+            }
+        } else if (phase != 1) {
+            // q is known (it came from the objective replica): exactly the consumer side of lpx_resident_primal --
+            // sleep through the owner's divide + store, one look at the row, else poll one granule (the last column).
+            __builtin_amdgcn_s_sleep(15);
+            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
+            bool first = true;
+            for (int base = t; base < C; base += RS_NT * RS_FETCH) {
+                int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < RS_FETCH; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < C) cnt = u + 1; }
+                unsigned pend = (1u << cnt) - 1u;
+                if (first && !rs_gather(xp, idx, cnt, gen, val, 1u, &pend)) {
+                    if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
+                }
+                first = false;
+                if (pend && !rs_gather(xp, idx, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
+#pragma unroll
+                for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) prow[idx[u]] = val[u];
+            }
+        } else {
+            // sleep through the owner's work, then ONE look at the header and the row together; if they are not all
+            // there yet, wait for the header alone (one granule) and gather what is missing.
+            __builtin_amdgcn_s_sleep(15);
+            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
+            if (phase == 1) __builtin_amdgcn_s_sleep(25);                       // the owner scans its row first
+            bool first = true;
+            double hq = 0.0; unsigned hpend = 1u;
+            for (int base = t; first || base < C; base += RS_NT * 3) {       // every lane fetches the header at least
+                int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < C) cnt = u + 1; }
+                unsigned pend = (1u << cnt) - 1u;
+                if (first) {
+                    idx[cnt] = ld;                                              // the header rides in the spare slot
+                    unsigned p2 = pend | (1u << cnt);
+                    rs_gather(xp, idx, cnt + 1, gen, val, 1u, &p2);
+                    if (!((p2 >> cnt) & 1u)) { hq = val[cnt]; hpend = 0u; }
+                    pend = p2 & ((1u << cnt) - 1u);
+                    if (hpend) {
+                        int hidx[RS_FETCH] = {ld, ld, ld, ld}; double hval[RS_FETCH];
+                        if (!rs_gather(xp, hidx, 1, gen, hval)) fail = 1;
+                        hq = hval[0]; hpend = 0u;
+                    }
+                    q = fail ? -1 : (int)hq;
+                    first = false;
+                }
+                if (q < 0) break;
+                if (pend && !rs_gather(xp, idx, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (u < cnt) prow[idx[u]] = val[u];
+            }
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+        if (q < 0) { r = -1; status = LPX_INFEASIBLE; break; }                  // :92-96 (dual loop only)
+
+        // ---- column factors of this pivot, objective replica, next entering column ------------------------------
+        if (t < nloc) fac[t] = tile[(size_t)t * ld + q];
+        if (t == RS_NT - 1) fac[rpw] = obj[q];
+        __syncthreads();
+        const double fobj = fac[rpw];
+        const int skip = (w == owner) ? rl : -1;
+        MinIdx best; best.v = -P.eps; best.i = INT_MAX;
+        if (t < RS_RT) {
+            for (int j = 2 * t; j < ld; j += 2 * RS_RT) {
+                const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                double2 o = *reinterpret_cast<double2*>(obj + j);
+                double prod = fobj * p.x; o.x = o.x - prod;
+                prod = fobj * p.y; o.y = o.y - prod;
+                *reinterpret_cast<double2*>(obj + j) = o;
+                if (j < rhsc && o.x < best.v) { best.v = o.x; best.i = j; }
+                if (j + 1 < rhsc && o.y < best.v) { best.v = o.y; best.i = j + 1; }
+            }
+        }
+        best = first4_min_idx(best, s_v, s_i);
+        if (w == 0 && t == 0) {
+            P.basis[r] = q;                                                     // basis[leaving] = entering, :110
+            if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        }
+        qlast = q;
+        ++iter;
+        if (phase == 0) ++fdf_count; else if (phase == 1) ++dual_iter; else ++primal_count;
+        qc = (phase != 1) ? (best.i == INT_MAX ? -1 : best.i) : -1;
+        // ---- lookahead: next round's (a, rhs) leave before the bulk of the update ---------------------------------
+        if (k + 1 < GP.chunk) {
+            if (t < nloc) {
+                double a = 0.0, rhs;
+                if (t == skip) { if (qc >= 0) a = prow[qc]; rhs = prow[rhsc]; }
+                else {
+                    const double f = fac[t];
+                    if (qc >= 0) { const double prod = f * prow[qc]; a = tile[(size_t)t * ld + qc] - prod; }
+                    const double prod2 = f * prow[rhsc]; rhs = tile[(size_t)t * ld + rhsc] - prod2;
+                }
+                u64* g = P.xr + 4 * ((size_t)(par ^ 1) * P.mcap + row0 + t);
+                rs_publish(g, a > P.eps ? rhs / a : __builtin_inf(), gen + 1u);
+                rs_publish(g + 2, rhs, gen + 1u);
+            }
+        }
+        __syncthreads();                        // the lookahead read columns qc and rhs before anyone rewrites them
+        // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + j);
+            for (int i = 0; i < nloc; ++i) {
+                if (i == skip) continue;
+                const double f = fac[i];
+                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                double prod = f * p.x; v.x = v.x - prod;
+                prod = f * p.y; v.y = v.y - prod;
+                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (hung) {
+        if (t == 0) atomicOr(&st->pad[1], 1);
+        return;
+    }
+    for (int i = 0; i < nloc; ++i) {
+        double* dst = P.T + (size_t)(row0 + i) * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(tile + (size_t)i * ld + j);
+    }
+    if (w == 0) {
+        double* dst = P.T + (size_t)m * ld;
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT)
+            *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(obj + j);
+        if (t == 0) {
+            st->status = status; st->iter = iter; st->phase = phase;
+            st->fdf_count = fdf_count; st->dual_iter = dual_iter; st->primal_count = primal_count;
+            st->r = status == LPX_RUNNING ? r : -1; st->q = status == LPX_RUNNING ? qlast : -1;
+            *P.xgen = gen;
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+size_t resident_group_lds(int R, int C, int ld, int grid)
+{
+    const int m = R - 1;
+    const int rpw = (m + grid - 1) / grid;
+    return sizeof(double) * ((size_t)(rpw + 2) * ld + 2 * (size_t)((m + 1) & ~1) + (size_t)rpw + 2);
+}
+
+hipError_t resident_group_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s)
+{
+    ResGroupParams p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
+    hipLaunchKernelGGL(lpx_resident_group, dim3(grid, nodes), dim3(RS_NT), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lpx

@@ -349,22 +349,35 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
     return p;
 }
 
+// Exchange buffers of the resident kernels (sized for both of them) and the basis snapshot, allocated on first use.
+static size_t xr_bytes(const lpx_tableau* t) { return sizeof(unsigned long long) * 8 * (size_t)t->Rcap; }
+static size_t xp_bytes(const lpx_tableau* t) { return sizeof(unsigned long long) * (4 * ((size_t)t->ld + 8) + 64); }   // + diagnostic stamps
+static int resident_buffers(lpx_tableau* t)
+{
+    if (t->xr) return 0;
+    LPX_HIP_TRY(hipMalloc((void**)&t->xr, xr_bytes(t)));
+    LPX_HIP_TRY(hipMalloc((void**)&t->xp, xp_bytes(t)));
+    LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
+    LPX_HIP_TRY(hipMalloc((void**)&t->xbasis, sizeof(int32_t) * (size_t)t->Rcap));
+    LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, xr_bytes(t), t->stream));
+    LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, xp_bytes(t), t->stream));
+    LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
+    return 0;
+}
+static void resident_buffers_clear(lpx_tableau* t)
+{
+    hipMemsetAsync(t->xr, 0, xr_bytes(t), t->stream);
+    hipMemsetAsync(t->xp, 0, xp_bytes(t), t->stream);
+    hipStreamSynchronize(t->stream);
+}
+
 // Resident primal loop: one launch runs up to `chunk` pivots with the tableau in LDS; the host only polls the
 // 64-byte state record between launches (and fires the pivot callbacks from the trace).
 int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* stats,
                  int grid, int rpw, size_t lds, int* resume_iter)
 {
     const int mcap = t->Rcap;
-    if (!t->xr) {
-        const size_t rb = sizeof(unsigned long long) * 4 * (size_t)mcap, pb = sizeof(unsigned long long) * (4 * (size_t)t->ld + 64);   // + diagnostic stamps
-        LPX_HIP_TRY(hipMalloc((void**)&t->xr, rb));
-        LPX_HIP_TRY(hipMalloc((void**)&t->xp, pb));
-        LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
-        LPX_HIP_TRY(hipMalloc((void**)&t->xbasis, sizeof(int32_t) * (size_t)mcap));
-        LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, rb, t->stream));
-        LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, pb, t->stream));
-        LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
-    }
+    { int rc = resident_buffers(t); if (rc) return rc; }
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
     *t->hst = init;
@@ -396,9 +409,7 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
         if (t->hst->pad[1]) {
             // a bounded wait expired: some workgroup was not resident or died; rows in HBM are those of the last
             // completed launch.  Clear the exchange buffers so that no stale generation can ever match.
-            hipMemsetAsync(t->xr, 0, sizeof(unsigned long long) * 4 * (size_t)mcap, t->stream);
-            hipMemsetAsync(t->xp, 0, sizeof(unsigned long long) * 4 * (size_t)t->ld, t->stream);
-            hipStreamSynchronize(t->stream);
+            resident_buffers_clear(t);
             set_error("resident loop: an exchange wait expired (workgroups not co-resident?)");
             // Nothing of this launch was written back (a workgroup that cannot finish keeps every other one from
             // finishing): the tableau is that of the previous launch; put its basis back and hand over to the
@@ -424,6 +435,137 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     local.pivots = t->hst->iter;
     if (stats) { const double h2d = stats->h2d_ms, d2h = stats->d2h_ms; *stats = local; stats->h2d_ms = h2d; stats->d2h_ms = d2h; }
     return status;
+}
+
+// Resident group run: the nodes of a batch are solved a few at a time, each resident in the LDS of its own slice
+// of the chip (lpx_resident_group.hip).  Launches are `chunk` pivots long; after each one finished nodes leave and
+// waiting ones take their place, so the slices stay busy until the batch is done.
+struct ResGroupBuf { ResNode* d = nullptr; ResNode* h = nullptr; DevState* hs = nullptr; int cap = 0; hipStream_t stream = nullptr; };
+ResGroupBuf g_resgroup;
+
+int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size_t* lds)
+{
+    hipDeviceProp_t prop; int dev = 0;
+    static int cus = 0;
+    if (!cus) { if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0; cus = prop.multiProcessorCount; }
+    const size_t lds_max = 160 * 1024 - 1024;
+    for (int n = count < 8 ? count : 8; n >= 1; --n) {
+        int g = cus / n;
+        size_t need = 0;
+        for (int i = 0; i < count; ++i) {
+            const int m = ts[i]->R - 1;
+            const int gi = g < m ? g : m;
+            const size_t b = resident_group_lds(ts[i]->R, ts[i]->C, ts[i]->ld, gi);
+            if (b > need) need = b;
+        }
+        int mmin = 1 << 30;
+        for (int i = 0; i < count; ++i) if (ts[i]->R - 1 < mmin) mmin = ts[i]->R - 1;
+        if (g > mmin) g = mmin;                       // at most one workgroup per row of the smallest node
+        if (g < 1) continue;
+        need = 0;
+        for (int i = 0; i < count; ++i) { const size_t b = resident_group_lds(ts[i]->R, ts[i]->C, ts[i]->ld, g); if (b > need) need = b; }
+        if (need <= lds_max) { *grid = g; *slots = n; *lds = need; return 1; }
+    }
+    return 0;
+}
+
+int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
+                       int* statuses, lpx_stats* stats, int grid, int slots, size_t lds, lpx_pivot_cb cb, void* user)
+{
+    ResGroupBuf& g = g_resgroup;
+    if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (g.cap < count) {
+        hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
+        g.d = nullptr; g.h = nullptr; g.hs = nullptr; g.cap = 0;
+        const int c = count + 16;
+        LPX_HIP_TRY(hipMalloc((void**)&g.d, sizeof(ResNode) * c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(ResNode) * c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&g.hs, sizeof(DevState) * c));
+        g.cap = c;
+    }
+    const double t0 = now_ms();
+    std::vector<ResNode> node(count);
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* t = ts[i];
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));                   // node assembly ran on the node's own stream
+        { int rc = resident_buffers(t); if (rc) return rc; }
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        const lpx_run_opts* o = dual[i] ? dopts : popts;
+        ResNode& n = node[i];
+        n.T = t->T; n.ld = t->ld; n.R = t->R; n.C = t->C; n.basis = t->basis; n.trace = t->trace; n.trace_cap = t->trace_cap;
+        n.st = t->st; n.xr = t->xr; n.xp = t->xp; n.xgen = t->xgen; n.mcap = t->Rcap; n.dual = dual[i] ? 1 : 0;
+        n.eps = o->eps; n.tol_fdf = o->ratio_tol; n.tol_dual = o->ratio_tol; n.tol_primal = dual[i] ? o->eps : o->ratio_tol;
+        n.max_iter = o->max_iter; n.fdf_guard = o->fdf_guard; n.cleanup = o->cleanup;
+        DevState init; std::memset(&init, 0, sizeof(init));
+        init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = dual[i] ? 0 : 2;
+        g.hs[i] = init;
+        LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[i], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
+        LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
+    }
+    // launch length: long enough to hide the launch + reload (~30 us), short enough that a node finishing inside a
+    // launch does not leave its slice idle for long
+    const lpx_run_opts* o0 = dual[0] ? dopts : popts;
+    const int chunk = cb ? (o0->batch > 0 ? o0->batch : 256) : (count > slots ? 96 : 1024);
+    std::vector<int> live(count);
+    for (int i = 0; i < count; ++i) live[i] = i;
+    std::vector<int> fired(count, 0);
+    long long launches = 0;
+    while (!live.empty()) {
+        const int n = (int)live.size() < slots ? (int)live.size() : slots;
+        for (int k = 0; k < n; ++k) g.h[k] = node[live[k]];
+        LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
+        LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
+        for (int k = 0; k < n; ++k)
+            LPX_HIP_TRY(hipMemcpyAsync(&g.hs[live[k]], ts[live[k]]->st, sizeof(DevState), hipMemcpyDeviceToHost, g.stream));
+        LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+        bool aborted = false;
+        for (int k = 0; k < n; ++k) if (g.hs[live[k]].pad[1]) aborted = true;
+        if (aborted) {
+            for (int k = 0; k < n; ++k) resident_buffers_clear(ts[live[k]]);
+            set_error("resident group loop: an exchange wait expired (workgroups not co-resident?)");
+            if (launches == 0) {
+                for (int i = 0; i < count; ++i)
+                    LPX_HIP_TRY(hipMemcpy(ts[i]->basis, ts[i]->xbasis, sizeof(int32_t) * (size_t)(ts[i]->R - 1), hipMemcpyDeviceToDevice));
+                return LPX_RESIDENT_RETRY;                   // nothing was written back: the caller streams the batch
+            }
+            return LPX_EDEVICE;
+        }
+        ++launches;
+        if (launches > 4LL * count * ((long long)popts->max_iter + dopts->max_iter + dopts->fdf_guard) / chunk + 64) {
+            set_error("resident group loop: launch budget exhausted while still running"); return LPX_ITER_LIMIT; }
+        std::vector<int> next;
+        for (int k = 0; k < n; ++k) {
+            const int i = live[k];
+            const DevState& s = g.hs[i];
+            if (cb && s.iter > fired[i]) {
+                lpx_tableau* t = ts[i];
+                const int lo = fired[i], hi = s.iter < t->trace_cap ? s.iter : t->trace_cap;
+                if (hi > lo) {
+                    std::vector<int32_t> tr(2 * (size_t)(hi - lo));
+                    LPX_HIP_TRY(hipMemcpy(tr.data(), t->trace + 2 * lo, sizeof(int32_t) * 2 * (hi - lo), hipMemcpyDeviceToHost));
+                    for (int z = lo; z < hi; ++z) cb(user, z + 1, tr[2 * (z - lo)], tr[2 * (z - lo) + 1]);
+                }
+                fired[i] = s.iter;
+            }
+            if (s.status == LPX_RUNNING) next.push_back(i);
+        }
+        for (size_t k = (size_t)n; k < live.size(); ++k) next.push_back(live[k]);
+        live.swap(next);
+    }
+    const double ms = now_ms() - t0;
+    for (int i = 0; i < count; ++i) {
+        const DevState& s = g.hs[i];
+        *ts[i]->hst = s;
+        statuses[i] = s.status;
+        if (stats) {
+            std::memset(&stats[i], 0, sizeof(lpx_stats));
+            stats[i].pivots = s.iter; stats[i].fdf_pivots = s.fdf_count;
+            stats[i].cleanup_pivots = dual[i] ? s.primal_count : 0;
+            stats[i].loop_ms = ms / (double)count;
+            stats[i].launches = launches;
+        }
+    }
+    return 0;
 }
 
 }  // namespace
@@ -593,6 +735,18 @@ int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     if (!t) { set_error("lpx_dual_run: null tableau"); return LPX_EINVAL; }
     lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
     if (t->R < 2) { set_error("lpx_dual_run: tableau needs at least one constraint row"); return LPX_EINVAL; }
+    static const bool res_env = [] { const char* e = std::getenv("LPX_RESIDENT"); return !(e && e[0] == '0'); }();
+    if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
+        int grid = 0, slots = 0; size_t lds = 0; int isdual = 1, status = 0;
+        if (!t->resident_off && resident_group_plan(&t, 1, &grid, &slots, &lds)) {
+            const int rc = run_resident_group(&t, &isdual, 1, o, o, &status, st, grid, slots, lds, cb, user);
+            if (rc == 0) return status;
+            if (rc != LPX_RESIDENT_RETRY) return rc;
+            t->resident_off = true;
+            if (o->resident > 0) return LPX_EDEVICE;
+        } else
+        if (o->resident > 0) { set_error("lpx_dual_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
+    }
     SelParams p = base_params(t, o, MODE_DUAL);
     long long budget = (long long)o->fdf_guard + 2LL * o->max_iter + 8;
     return run_loop(t, p, o, budget, cb, user, st);
@@ -818,6 +972,20 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
     lpx_run_opts pd, dd;
     if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
     if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
+    // Nodes small enough to live on chip a few at a time (lpx_resident_group.hip).  Opt-in (LPX_RESIDENT_GROUP=1): on the
+    // degenerate 0/1 programs of config 4 the exact hysteresis scan dominates every pivot and three resident nodes are
+    // no faster than 32 streaming ones (251 vs 267 LP/s), so the batched streaming run stays the default.
+    static const bool resgroup_env = [] { const char* e = std::getenv("LPX_RESIDENT_GROUP"); return e && e[0] == '1'; }();
+    if (resgroup_env && count >= 1 && !popts->profile && !dopts->profile && popts->resident >= 0 && dopts->resident >= 0) {
+        bool ok = true;
+        for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2 || ts[i]->resident_off) ok = false;
+        int grid = 0, slots = 0; size_t lds = 0;
+        if (ok && resident_group_plan(ts, count, &grid, &slots, &lds)) {
+            const int rc = run_resident_group(ts, dual, count, popts, dopts, statuses, stats, grid, slots, lds, nullptr, nullptr);
+            if (rc != LPX_RESIDENT_RETRY) return rc;
+            for (int i = 0; i < count; ++i) ts[i]->resident_off = true;
+        }
+    }
     static const bool batched_env = [] { const char* e = std::getenv("LPX_BATCHED"); return !(e && e[0] == '0'); }();
     if (batched_env && count >= 2 && !popts->profile && !dopts->profile) {
         bool ok = true;

@@ -17,7 +17,7 @@ if "rev" in which:
 if "bnb" in which or "wide" in which:
     c, A, rel, b = synth.binary_ip(512, 256)
     p = L.LPProblem.from_arrays(0, c, A, rel, b)
-    for (mode, search, cn, mx) in ([(0, 0, 1, 16), (1, 0, 1, 12), (1, 1, 4, 24), (1, 1, 8, 48)] if 'wide' not in which else [(1, 2, 64, 1600)] if 'dive' not in which else [(1, 2, 64, 20000), (1, 1, 32, 1500)]):
+    for (mode, search, cn, mx) in ([(0, 0, 1, 16), (1, 0, 1, 12), (1, 1, 4, 24), (1, 1, 8, 48)] if 'wide' not in which else [(1, 2, 64, 1600)] if 'dive' not in which and 'cold' not in which else [(1, 1, 32, 400), (1, 1, 64, 400), (1, 1, 12, 400)] if 'cold' in which else [(1, 2, 64, 20000), (1, 1, 32, 1500)]):
         t = time.perf_counter()
         r = L.BranchAndBound(bnb_mode=mode, bnb_search=search, concurrent_nodes=cn, max_nodes=mx, bnb_dive=1 if "dive" in which else 0).Solve(p)
         dt = time.perf_counter() - t
