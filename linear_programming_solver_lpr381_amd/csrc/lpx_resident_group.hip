@@ -21,6 +21,14 @@ namespace lpx {
 
 struct ResGroupParams { const ResNode* nodes; int chunk; };
 
+#ifdef LPX_STAMPS
+#define RG_T0 unsigned long long rg_prev_ = __builtin_amdgcn_s_memtime();
+#define RG_T(slot) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1 ? 1 : 0) && blockIdx.y == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); P.xp[4 * ((size_t)P.ld + 8) + (slot)] += n_ - rg_prev_; rg_prev_ = n_; } } while (0)
+#else
+#define RG_T0
+#define RG_T(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ int first4_first_min_below(const double* v, int L, double eps, double* s_v, int* s_i)
 {
     MinIdx m; m.v = -eps; m.i = INT_MAX;
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     int qc = (phase != 1) ? first4_first_min_below(obj, rhsc, P.eps, s_v, s_i) : -1;
     bool publish_now = GP.chunk > 0;            // rows' (a, rhs) for the first round of this launch
 
+    RG_T0
     for (int k = 0; k < GP.chunk; ++k) {
         if (publish_now) {
             if (t < nloc) {
@@ -102,6 +111,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             if (i1 < m) { colA[i1] = val[2]; colB[i1] = val[3]; }
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
+        RG_T(1);
 
         // ---- the decision of lpx_select_body, replicated ------------------------------------------------------------
         int q = -1, final_status = LPX_RUNNING;
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         if (republish) { publish_now = true; continue; }                        // one exchange round without a pivot
         if (final_status != LPX_RUNNING || r < 0) { status = (final_status == LPX_RUNNING) ? LPX_OPTIMAL : final_status; break; }
 
+        RG_T(2);
         // ---- exchange 2: the owner normalises row r (and, in the dual loop, chooses the entering column) ---------
         const int owner = r / rpw, rl = r - owner * rpw;
         u64* xp = P.xp + 2 * (size_t)par * (ld + 8);
@@ -217,6 +228,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
         if (q < 0) { r = -1; status = LPX_INFEASIBLE; break; }                  // :92-96 (dual loop only)
+        RG_T(3);
 
         // ---- column factors of this pivot, objective replica, next entering column ------------------------------
         if (t < nloc) fac[t] = tile[(size_t)t * ld + q];
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         ++iter;
         if (phase == 0) ++fdf_count; else if (phase == 1) ++dual_iter; else ++primal_count;
         qc = (phase != 1) ? (best.i == INT_MAX ? -1 : best.i) : -1;
+        RG_T(4);
         // ---- lookahead: next round's (a, rhs) leave before the bulk of the update ---------------------------------
         if (k + 1 < GP.chunk) {
             if (t < nloc) {
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             }
         }
         __syncthreads();                        // the lookahead read columns qc and rhs before anyone rewrites them
+        RG_T(0);
         // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
         for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
             const double2 p = *reinterpret_cast<const double2*>(prow + j);
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             }
         }
         __syncthreads();
+        RG_T(5);
     }
 
     if (hung) {

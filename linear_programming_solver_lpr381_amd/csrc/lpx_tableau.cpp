@@ -249,6 +249,13 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
 }
 
 #ifdef LPX_STAMPS
+int lpx_debug_resident_group(lpx_tableau* t, unsigned long long* out, int n, int clear)
+{
+    if (!t->xp) return LPX_EINVAL;
+    LPX_HIP_TRY(hipMemcpy(out, t->xp + 4 * ((size_t)t->ld + 8), sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (clear) LPX_HIP_TRY(hipMemset(t->xp + 4 * ((size_t)t->ld + 8), 0, sizeof(unsigned long long) * n));
+    return 0;
+}
 int lpx_debug_resident(lpx_tableau* t, unsigned long long* out, int n, int clear)
 {
     if (!t->xp) return LPX_EINVAL;
@@ -462,6 +469,12 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
         for (int i = 0; i < count; ++i) if (ts[i]->R - 1 < mmin) mmin = ts[i]->R - 1;
         if (g > mmin) g = mmin;                       // at most one workgroup per row of the smallest node
         if (g < 1) continue;
+        {   // no idle workgroups: the fewest that keep the same rows-per-workgroup for the tallest node
+            int mmax = 1;
+            for (int i = 0; i < count; ++i) if (ts[i]->R - 1 > mmax) mmax = ts[i]->R - 1;
+            const int rpw = (mmax + g - 1) / g;
+            g = (mmax + rpw - 1) / rpw;
+        }
         need = 0;
         for (int i = 0; i < count; ++i) { const size_t b = resident_group_lds(ts[i]->R, ts[i]->C, ts[i]->ld, g); if (b > need) need = b; }
         if (need <= lds_max) { *grid = g; *slots = n; *lds = need; return 1; }
