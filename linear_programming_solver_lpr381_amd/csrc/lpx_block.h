@@ -159,7 +159,9 @@ __device__ unsigned long long lpx_g_stamps[32];
 #define LPX_HS_BEGIN
 #endif
 
-template <class Src>
+// FLY = true: sources in LDS -- each ratio is formed as soon as its two operands are read, so only the 16 ratios
+// stay live (32 VGPRs instead of 96; the resident kernels have 128 per lane and spill otherwise).
+template <class Src, bool FLY = false>
 __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src)
 {
     const int lane = threadIdx.x & 63;
@@ -167,7 +169,18 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
     int win = -1;
     LPX_HS_BEGIN
     for (int seg = 0; seg < L; seg += 64 * WH_PER) {
-        double den[WH_PER], num[WH_PER], rt[WH_PER];
+        double rt[WH_PER];
+        if constexpr (FLY) {
+#pragma unroll
+            for (int u = 0; u < WH_PER; ++u) {
+                const int k = seg + u * 64 + lane;
+                const int kc = min(k, L - 1);
+                const double v = src.value(src.den(kc), src.num(kc));
+                rt[u] = (k < L) ? v : __builtin_inf();
+                __builtin_amdgcn_sched_barrier(0);      // one ratio (and its division) at a time: keeps the live set small
+            }
+        } else {
+        double den[WH_PER], num[WH_PER];
 #pragma unroll
         for (int u = 0; u < WH_PER; ++u) {
             // clamped index instead of a guard: a guarded load becomes its own exec-masked branch with
@@ -181,6 +194,7 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
         for (int u = 0; u < WH_PER; ++u) {
             const int k = seg + u * 64 + lane;
             rt[u] = (k < L) ? src.value(den[u], num[u]) : __builtin_inf();
+        }
         }
         LPX_HS(1);
         // Fast path.  Let rmin be the segment minimum and i* its first position.  No row of the segment

@@ -95,6 +95,17 @@ struct LdsRatio {
     __device__ __forceinline__ double value(double a, double) const { return a; }
 };
 
+// The exact wave-0 replays are real calls: inlined, their 16-ratio register blocks push the 1024-lane kernels (128
+// VGPRs per lane) into scratch spills on the hot path; as calls they cost a few saves only when a tie needs them.
+__device__ __attribute__((noinline)) int rs_exact_row_scan(int m, double tol, const double* ratios)
+{
+    return wave_hysteresis_argmin<LdsRatio, true>(m, tol, LdsRatio{ratios});
+}
+__device__ __attribute__((noinline)) int rs_exact_col_scan(int L, double tol, const double* row, const double* zrow, double eps)
+{
+    return wave_hysteresis_argmin<DualColRatio, true>(L, tol, DualColRatio{row, zrow, eps});
+}
+
 // The hysteresis scan of Models/PrimalSimplex.cs:234-241 over `ratios[0..m)` in LDS (+inf = ineligible), identical
 // in every workgroup.  Fast path (lpx_block.h, wave_hysteresis_argmin): with rmin the smallest ratio and i* its first
 // row, if no OTHER row j has fl(r_j - tol) <= rmin the sequential scan ends at i* whatever it accepted on the way.
@@ -119,7 +130,7 @@ __device__ __forceinline__ int rs_hysteresis(int m, double tol, const double* ra
         if (s_i[4] + s_i[5] + s_i[6] + s_i[7] == 1) r = lm.i;
         else {
             if ((t >> 6) == 0) {
-                const int win = wave_hysteresis_argmin(m, tol, LdsRatio{ratios});
+                const int win = rs_exact_row_scan(m, tol, ratios);
                 if (t == 0) *s_out = win;
             }
             __syncthreads();

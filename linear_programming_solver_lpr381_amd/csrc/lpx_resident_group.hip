@@ -46,8 +46,11 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     __shared__ int s_i[RS_NT / 64];
     __shared__ int s_out;
 
-    const ResNode P = GP.nodes[blockIdx.y];
-    DevState* st = P.st;
+    const ResNode& N = GP.nodes[blockIdx.y];   // rarely used fields are read from the record where they are needed
+    struct { double* T; int ld, R, C; unsigned long long* xr; unsigned long long* xp; int mcap, dual; } P;
+    P.T = N.T; P.ld = N.ld; P.R = N.R; P.C = N.C; P.xr = N.xr; P.xp = N.xp; P.mcap = N.mcap; P.dual = N.dual;
+    const double eps = N.eps;
+    DevState* st = N.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
     const int ld = P.ld, C = P.C, m = P.R - 1, rhsc = C - 1;
@@ -78,22 +81,28 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
 
     int phase = P.dual ? st->phase : 2;
     int fdf_count = st->fdf_count, dual_iter = st->dual_iter, primal_count = st->primal_count, iter = st->iter;
-    unsigned gen = *P.xgen;
+    unsigned gen = *N.xgen;
     int status = LPX_RUNNING;
     bool hung = false;
     int r = -1, qlast = -1;
     // entering column the primal-like phases would take now (ChooseEntering, Models/PrimalSimplex.cs:205-220)
-    int qc = (phase != 1) ? first4_first_min_below(obj, rhsc, P.eps, s_v, s_i) : -1;
+    int qc = (phase != 1) ? first4_first_min_below(obj, rhsc, eps, s_v, s_i) : -1;
     bool publish_now = GP.chunk > 0;            // rows' (a, rhs) for the first round of this launch
 
     RG_T0
+    const int t_outer = t;
     for (int k = 0; k < GP.chunk; ++k) {
+        // Opaque per-round copy of the lane index: without it the compiler hoists dozens of lane-dependent addresses
+        // out of the round loop, runs out of the 128 VGPRs a 1024-lane workgroup gets and reloads them from scratch
+        // on the critical path (the owner's publish loop waited ~1 us for three scratch loads).
+        int t = t_outer;
+        asm volatile("" : "+v"(t));
         if (publish_now) {
             if (t < nloc) {
                 u64* g = P.xr + 4 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t);
                 const double rhs0 = tile[(size_t)t * ld + rhsc];
                 const double a0 = qc >= 0 ? tile[(size_t)t * ld + qc] : 0.0;
-                rs_publish(g, a0 > P.eps ? rhs0 / a0 : __builtin_inf(), gen + 1u);        // ratio of :229-233
+                rs_publish(g, a0 > eps ? rhs0 / a0 : __builtin_inf(), gen + 1u);        // ratio of :229-233
                 rs_publish(g + 2, rhs0, gen + 1u);
             }
             publish_now = false;
@@ -118,29 +127,25 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         bool republish = false;
         r = -1;
         for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0 && !republish; ++hop) {
-            if (phase == 0) {                                                   // ForceDualFeasibility, :195-228
-                if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
-                q = qc;
-                if (q < 0) { phase = 1; continue; }
-                r = rs_hysteresis(m, P.tol_fdf, colA, s_v, s_i, &s_out);
-                if (r < 0) { q = -1; phase = 1; continue; }
-            } else if (phase == 1) {                                            // dual loop, :36-113
-                if (dual_iter >= P.max_iter) { final_status = LPX_ITER_LIMIT; break; }
-                r = first4_first_min_below(colB, m, P.eps, s_v, s_i);           // most negative RHS, first index (:45-55)
+            if (phase == 1) {                                                   // dual loop, Models/DualSimplex.cs:36-113
+                if (dual_iter >= N.max_iter) { final_status = LPX_ITER_LIMIT; break; }
+                r = first4_first_min_below(colB, m, eps, s_v, s_i);             // most negative RHS, first index (:45-55)
                 if (r < 0) {
-                    if (P.cleanup) {
-                        const int qe = first4_first_min_below(obj, rhsc, P.eps, s_v, s_i);
-                        if (qe >= 0) { phase = 2; qc = qe; republish = true; break; }   // the rows' a_i for qe are not out yet
+                    if (N.cleanup) {
+                        const int qe = first4_first_min_below(obj, rhsc, eps, s_v, s_i);
+                        if (qe >= 0) { phase = 2; qc = qe; republish = true; break; }   // the rows' ratios for qe are not out yet
                     }
                     final_status = LPX_OPTIMAL; break;
                 }
                 q = -2;                                                         // chosen by the owner of row r below
-            } else {                                                            // primal loop, PrimalSimplex.cs:92-124
-                if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
+            } else {
+                // ForceDualFeasibility (phase 0, :195-228) and the primal loop (phase 2, PrimalSimplex.cs:92-124)
+                if (phase == 0 && fdf_count >= N.fdf_guard) { phase = 1; continue; }
+                if (phase == 2 && primal_count >= N.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
                 q = qc;
-                if (q < 0) { final_status = LPX_OPTIMAL; break; }
-                r = rs_hysteresis(m, P.tol_primal, colA, s_v, s_i, &s_out);
-                if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
+                if (q < 0) { if (phase == 0) { phase = 1; continue; } final_status = LPX_OPTIMAL; break; }
+                r = rs_hysteresis(m, phase == 0 ? N.tol_fdf : N.tol_primal, colA, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; if (phase == 0) { phase = 1; continue; } final_status = LPX_UNBOUNDED; break; }
             }
         }
         if (republish) { publish_now = true; continue; }                        // one exchange round without a pivot
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             double* prw = tile + (size_t)rl * ld;
             if (phase == 1) {                                                   // entering column of the dual loop, :79-91
                 if ((t >> 6) == 0) {
-                    const int win = wave_hysteresis_argmin(rhsc, P.tol_dual, DualColRatio{prw, obj, P.eps});
+                    const int win = rs_exact_col_scan(rhsc, N.tol_dual, prw, obj, eps);
                     if (t == 0) s_out = win;
                 }
                 __syncthreads();
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         __syncthreads();
         const double fobj = fac[rpw];
         const int skip = (w == owner) ? rl : -1;
-        MinIdx best; best.v = -P.eps; best.i = INT_MAX;
+        MinIdx best; best.v = -eps; best.i = INT_MAX;
         if (t < RS_RT) {
             for (int j = 2 * t; j < ld; j += 2 * RS_RT) {
                 const double2 p = *reinterpret_cast<const double2*>(prow + j);
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         }
         best = first4_min_idx(best, s_v, s_i);
         if (w == 0 && t == 0) {
-            P.basis[r] = q;                                                     // basis[leaving] = entering, :110
-            if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+            N.basis[r] = q;                                                     // basis[leaving] = entering, :110
+            if (iter < N.trace_cap) { N.trace[2 * iter] = r; N.trace[2 * iter + 1] = q; }
         }
         qlast = q;
         ++iter;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
                     const double prod2 = f * prow[rhsc]; rhs = tile[(size_t)t * ld + rhsc] - prod2;
                 }
                 u64* g = P.xr + 4 * ((size_t)(par ^ 1) * P.mcap + row0 + t);
-                rs_publish(g, a > P.eps ? rhs / a : __builtin_inf(), gen + 1u);
+                rs_publish(g, a > eps ? rhs / a : __builtin_inf(), gen + 1u);
                 rs_publish(g + 2, rhs, gen + 1u);
             }
         }
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             st->status = status; st->iter = iter; st->phase = phase;
             st->fdf_count = fdf_count; st->dual_iter = dual_iter; st->primal_count = primal_count;
             st->r = status == LPX_RUNNING ? r : -1; st->q = status == LPX_RUNNING ? qlast : -1;
-            *P.xgen = gen;
+            *N.xgen = gen;
         }
     }
 }
