@@ -13,6 +13,8 @@ using namespace lpx;
 struct lpx_tableau {
     int R = 0, C = 0, ld = 0;   // live shape (<= capacity) and leading dimension (from the capacity)
     int Rcap = 0, Ccap = 0;
+    char* slab = nullptr;       // device slab holding every small buffer below (all but T)
+    char* hslab = nullptr;      // pinned slab holding hst and shape_h
     int32_t* shape = nullptr;   // device record {R, C} read by the kernels
     int32_t* shape_h = nullptr; // pinned staging
     double* T = nullptr;        // [R*ld]
@@ -117,47 +119,52 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     const size_t tb = sizeof(double) * (size_t)R * t->ld;
     const int wsn = R > C ? R : C;
     t->trace_cap = 1 << 16;
-#define ALLOC(ptr, bytes)                                                                     \
-    do {                                                                                      \
-        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                   \
-        if (e_ != hipSuccess) {                                                               \
-            set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_));             \
-            lpx_tableau_destroy(t);                                                           \
-            return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE;                      \
-        }                                                                                     \
-    } while (0)
-    ALLOC(t->T, tb);
-    ALLOC(t->prow, sizeof(double) * t->ld);
-    ALLOC(t->pcol, sizeof(double) * R);
-    ALLOC(t->col0, sizeof(double) * R);
-    ALLOC(t->col1, sizeof(double) * R);
-    ALLOC(t->rhsbuf, sizeof(double) * R);
-    ALLOC(t->ws, sizeof(double) * (size_t)wsn * 32);
-    ALLOC(t->part_v, sizeof(double) * 192);   // [128..191]: diagnostic stamps (LPX_STAMPS builds only)
-    ALLOC(t->part_i, sizeof(int32_t) * 128);
-    ALLOC(t->us, sizeof(DevState));
-    ALLOC(t->basis, sizeof(int32_t) * (R > 1 ? R - 1 : 1));
-    ALLOC(t->trace, sizeof(int32_t) * 2 * t->trace_cap);
-    ALLOC(t->st, sizeof(DevState));
-    ALLOC(t->shape, sizeof(int32_t) * 2);
-#undef ALLOC
-    if (hipHostMalloc((void**)&t->hst, sizeof(DevState)) != hipSuccess ||
-        hipHostMalloc((void**)&t->shape_h, sizeof(int32_t) * 2) != hipSuccess ||
+    // One device slab for the tableau and one for everything small around it, one pinned slab for the host mirrors:
+    // a B&B pool creates dozens of handles per solve, and 14 hipMallocs + 2 hipHostMallocs each cost 4 ms per handle.
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nb = R > 1 ? (size_t)R - 1 : 1;
+    const size_t sz[] = { up(sizeof(double) * t->ld), up(sizeof(double) * R), up(sizeof(double) * R), up(sizeof(double) * R),
+                          up(sizeof(double) * R), up(sizeof(double) * (size_t)wsn * 32), up(sizeof(double) * 192),
+                          up(sizeof(int32_t) * 128), up(sizeof(DevState)), up(sizeof(int32_t) * nb),
+                          up(sizeof(int32_t) * 2 * (size_t)t->trace_cap), up(sizeof(DevState)), up(sizeof(int32_t) * 2) };
+    size_t total = 0;
+    for (size_t b : sz) total += b;
+    hipError_t e_ = hipMalloc((void**)&t->T, tb);
+    if (e_ == hipSuccess) e_ = hipMalloc((void**)&t->slab, total);
+    if (e_ != hipSuccess) {
+        set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_));
+        lpx_tableau_destroy(t);
+        return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE;
+    }
+    {
+        char* p = t->slab; int k = 0;
+        t->prow = (double*)p; p += sz[k++];
+        t->pcol = (double*)p; p += sz[k++];
+        t->col0 = (double*)p; p += sz[k++];
+        t->col1 = (double*)p; p += sz[k++];
+        t->rhsbuf = (double*)p; p += sz[k++];
+        t->ws = (double*)p; p += sz[k++];
+        t->part_v = (double*)p; p += sz[k++];      // [128..191]: diagnostic stamps (LPX_STAMPS builds only)
+        t->part_i = (int32_t*)p; p += sz[k++];
+        t->us = (DevState*)p; p += sz[k++];
+        t->basis = (int32_t*)p; p += sz[k++];
+        t->trace = (int32_t*)p; p += sz[k++];
+        t->st = (DevState*)p; p += sz[k++];
+        t->shape = (int32_t*)p; p += sz[k++];
+    }
+    if (hipHostMalloc((void**)&t->hslab, 256 + sizeof(int32_t) * 2) != hipSuccess ||
         hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("host-pinned state / stream creation failed");
         lpx_tableau_destroy(t);
         return LPX_EDEVICE;
     }
+    t->hst = (DevState*)t->hslab; t->shape_h = (int32_t*)(t->hslab + 256);
+    static_assert(sizeof(DevState) <= 256, "pinned slab layout");
+    hipMemsetAsync(t->T, 0, tb, t->stream);
+    hipMemsetAsync(t->slab, 0, total - sz[10] - sz[11] - sz[12], t->stream);      // everything in front of the trace
+    hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream);
     t->shape_h[0] = R; t->shape_h[1] = C;
     hipMemcpyAsync(t->shape, t->shape_h, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream);
-    hipMemsetAsync(t->T, 0, tb, t->stream);
-    hipMemsetAsync(t->prow, 0, sizeof(double) * t->ld, t->stream);
-    hipMemsetAsync(t->pcol, 0, sizeof(double) * R, t->stream);
-    hipMemsetAsync(t->col0, 0, sizeof(double) * R, t->stream);
-    hipMemsetAsync(t->col1, 0, sizeof(double) * R, t->stream);
-    hipMemsetAsync(t->rhsbuf, 0, sizeof(double) * R, t->stream);
-    hipMemsetAsync(t->basis, 0, sizeof(int32_t) * (R > 1 ? R - 1 : 1), t->stream);
-    hipMemsetAsync(t->st, 0, sizeof(DevState), t->stream);
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));
     *out = t;
     return 0;
@@ -169,13 +176,11 @@ void lpx_tableau_destroy(lpx_tableau* t)
     if (t->stream) hipStreamSynchronize(t->stream);
     drop_graph(t);
     for (hipEvent_t e : t->events) hipEventDestroy(e);
-    hipFree(t->T); hipFree(t->snapT); hipFree(t->prow); hipFree(t->pcol); hipFree(t->col0); hipFree(t->col1); hipFree(t->rhsbuf); hipFree(t->ws); hipFree(t->part_v); hipFree(t->part_i); hipFree(t->us);
-    hipFree(t->basis); hipFree(t->snapBasis); hipFree(t->trace); hipFree(t->st);
-    hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf); hipFree(t->shape);
+    hipFree(t->T); hipFree(t->slab); hipFree(t->snapT); hipFree(t->snapBasis);
+    hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf);
     hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis);
-    if (t->shape_h) hipHostFree(t->shape_h);
+    if (t->hslab) hipHostFree(t->hslab);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
-    if (t->hst) hipHostFree(t->hst);
     if (t->stream) hipStreamDestroy(t->stream);
     delete t;
 }

@@ -17,3 +17,17 @@ with L.DeviceTableau.from_host(T, basis) as dt:
         dt.restore()
         status, st = dt.dual_run(L.default_opts(True, fdf_guard=100000, cleanup=1, resident=1))
     print(f"  group kernel (dual entry): status={status} pivots={st['pivots']} fdf={st['fdf_pivots']} {1e3*st['loop_ms']/st['pivots']:.2f} us/pivot")
+    # three (or six) copies of the same node through lpx_multi_run on the group kernel: the cost of sharing the chip
+os.environ.setdefault("LPX_RESIDENT_GROUP", "1")
+import time
+for ncopy in (1, 3, 6):
+    hs = [L.DeviceTableau.from_host(T, basis) for _ in range(ncopy)]
+    o = L.default_opts(True, fdf_guard=100000, cleanup=1)
+    L.multi_run(hs, [1] * ncopy, dual_opts=o)
+    for h in hs: h.upload(T, basis)
+    t0 = time.perf_counter()
+    sts, stats = L.multi_run(hs, [1] * ncopy, dual_opts=o)
+    dt_ = time.perf_counter() - t0
+    piv = sum(s["pivots"] for s in stats)
+    print(f"  multi_run x{ncopy}: {piv} pivots in {dt_*1e3:.2f} ms -> {piv/dt_:,.0f} pivots/s aggregate ({dt_*1e6*min(ncopy,3)/piv:.2f} us per pivot per resident node), launches {stats[0]['launches']}")
+    for h in hs: h.close()
