@@ -46,23 +46,44 @@ static PhaseTimer g_pt;
 
 std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b; }
 
-// pool of device tableaux keyed by shape: nodes of one depth share a shape
+// pool of device tableaux keyed by shape: nodes of one depth share a shape.  Creating a handle costs ~4 ms (device and
+// pinned allocations, a stream) and destroying it ~3 ms, so handles outlive the solve that made them: a finished pool
+// parks them in a process-wide cache (bounded) and the next solve of the same shape class takes them from there.
+struct HandleCache {
+    std::map<std::pair<int, int>, std::vector<lpx_tableau*>> free_;
+    size_t count = 0;
+    static constexpr size_t kMax = 512;
+    lpx_tableau* take(int R, int C) {
+        auto it = free_.find({R, C});
+        if (it == free_.end() || it->second.empty()) return nullptr;
+        lpx_tableau* t = it->second.back(); it->second.pop_back(); --count;
+        return t;
+    }
+    void park(lpx_tableau* t, int R, int C) {
+        if (count >= kMax) { lpx_tableau_destroy(t); return; }
+        free_[{R, C}].push_back(t); ++count;
+    }
+};
+static HandleCache g_handle_cache;     // never destroyed: the HIP runtime may be gone by the time statics are torn down
+
 struct HandlePool {
     std::map<std::pair<int, int>, std::vector<lpx_tableau*>> free_;
     std::vector<lpx_tableau*> all_;
     lpx_tableau* get(int R, int C) {
         auto& v = free_[{R, C}];
         if (!v.empty()) { lpx_tableau* t = v.back(); v.pop_back(); return t; }
-        lpx_tableau* t = nullptr;
-        int rc = lpx_tableau_create(R, C, &t);
-        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        lpx_tableau* t = g_handle_cache.take(R, C);
+        if (!t) {
+            int rc = lpx_tableau_create(R, C, &t);
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        }
         all_.push_back(t);
         cap_[t] = {R, C};
         return t;
     }
     std::map<lpx_tableau*, std::pair<int, int>> cap_;
     void put(lpx_tableau* t) { free_[cap_[t]].push_back(t); }
-    ~HandlePool() { for (lpx_tableau* t : all_) lpx_tableau_destroy(t); }
+    ~HandlePool() { for (lpx_tableau* t : all_) g_handle_cache.park(t, cap_[t].first, cap_[t].second); }
 };
 
 struct NodeLP {
