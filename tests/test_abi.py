@@ -55,3 +55,29 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/lpx.h must be consumable by a C compiler (the boundary is a C ABI, not a C++ API), and a C client must
+    link against liblpx.so with nothing but the header.  No GPU call is made: lpx_abi_version / lpx_format_number only."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "lpx.h")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    so = os.path.join(root, "linear_programming_solver_lpr381_amd", "liblpx.so")
+    if not os.path.exists(so):
+        pytest.skip("liblpx.so not built")
+    src = tmp_path / "client.c"
+    src.write_text('#include "lpx.h"\n#include <stdio.h>\n'
+                   'int main(void) { char b[32]; lpx_run_opts o; lpx_default_opts(&o, 0);\n'
+                   '  lpx_format_number(2.5, b, (int)sizeof b);\n'
+                   '  printf("%d %s %d %g\\n", lpx_abi_version(), b, o.max_iter, o.eps); return 0; }\n')
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(so)
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-llpx",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "1" and out[1] == "2.5" and out[2] == "10000" and float(out[3]) == 1e-9
