@@ -106,7 +106,10 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     __syncthreads();
 
     RS_T0
+    const int t_outer = t;
     for (int k = 0; k < P.chunk; ++k) {
+        int t = t_outer;                        // opaque per-round copy: keeps lane-dependent addresses from being
+        asm volatile("" : "+v"(t));              // hoisted out of the round loop and held in registers (see lpx_resident_group.hip)
         if (iter >= P.max_iter) { status = LPX_ITER_LIMIT; break; }            // :95-96
         if (q < 0) { status = LPX_OPTIMAL; break; }                             // :99
         ++gen;
