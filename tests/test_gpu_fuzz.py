@@ -1,4 +1,4 @@
-"""GPU parity fuzz: a compact run of tools/fuzz_parity.py (random shapes incl. > 1024 rows, integer /
+"""GPU parity fuzz: a compact run of tests/fuzz_parity.py (random shapes incl. > 1024 rows, integer /
 degenerate / near-tie data, primal and dual loops, eager / graph / batched group execution), bitwise."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [1, 2])
 def test_randomized_parity_sweep(gpu, oracle, seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seed), "150"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), str(seed), "150"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout

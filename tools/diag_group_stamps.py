@@ -8,7 +8,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import linear_programming_solver_lpr381_amd as L
 from linear_programming_solver_lpr381_amd import synth
-from oracle import oracle as O
 
 lib = L._lib.lib()
 c, A, rel, b = synth.binary_ip(512, 256)
