@@ -57,6 +57,19 @@ def test_product_never_references_the_oracle():
                 assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_use_the_oracle():
+    """tools/ never imports the oracle; bench.py does so only inside its cpu_baseline leg; __graft_entry__ only in
+    build() (compiling the checker) and smoke() (checking one result)."""
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", f), errors="replace").read()
+            assert "import oracle" not in txt and "from oracle" not in txt, f"tools/{f} uses the oracle"
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    first = bench.index("from oracle import")
+    assert bench.count("from oracle import") == 1 and bench.index("CPU baseline") < first, "oracle import outside the cpu_baseline leg"
+    assert "if world == 1:" in bench[bench.index("CPU baseline"):first]
+
+
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     """include/lpx.h must be consumable by a C compiler (the boundary is a C ABI, not a C++ API), and a C client must
     link against liblpx.so with nothing but the header.  No GPU call is made: lpx_abi_version / lpx_format_number only."""
