@@ -392,6 +392,13 @@ def main():
                                    "sample": f"all {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
                                              f"(gcc -O2 -ffp-contract=off, scalar), {cpu_s:.1f} s"}
             progress(f"CPU 1-core done ({cpu_s:.1f} s); all-cores baseline")
+            try:
+                model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                model = "unknown"
+            out["cpu_baseline"]["cpu_model"] = model
+            out["cpu_baseline"]["nproc"] = os.cpu_count()
+            out["cpu_baseline"]["affinity_cpus"] = len(os.sched_getaffinity(0))
             # courtesy strong baseline: the same loop with Pivot's rows spread over all host cores
             # the box grants 16 CPUs per GPU whatever the affinity mask says; oversubscribed OpenMP
             # teams spin in their barriers, so cap the team and make idle threads sleep
