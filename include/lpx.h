@@ -230,6 +230,14 @@ int  lpx_knapsack_order(lpx_knapsack* k, int32_t* order /* [n]: ratio rank -> or
 int  lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
                               const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
                               double* frac_val);
+/* Same, plus each node's two children in the same launch: outputs have 3*count entries, slot 3k = node k itself,
+ * 3k+1 / 3k+2 = node k with its fractional item (the one the search branches on, :180) additionally fixed to 0 / 1 --
+ * what the best-first loop (:207-209, :267-269) asks for when it pops node k.  frac_idx = -2 in the child slots when
+ * node k has no fractional item.  Needs non-negative weights (lpx_knapsack_has_prefix). */
+int  lpx_knapsack_relax_batch2(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
+                               const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                               double* frac_val);
+int  lpx_knapsack_has_prefix(lpx_knapsack* k);
 
 /* ---- model level: the reference's plugin boundary through a C ABI ------------------------------ */
 /* `ILPAlgorithm.Solve(LPProblem, Action<string,bool[,]>) -> SimplexResult` (Models/IPLAlgorithm.cs:5-8)

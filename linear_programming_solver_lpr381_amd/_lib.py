@@ -162,6 +162,7 @@ def lib() -> C.CDLL:
     L.lpx_knapsack_destroy.restype = None
     L.lpx_knapsack_order.argtypes = [vp, ip]
     L.lpx_knapsack_relax_batch.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
+    L.lpx_knapsack_relax_batch2.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
     L.lpx_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
     L.lpx_default_solve_opts.restype = None
     L.lpx_solve.argtypes = [C.POINTER(Problem), C.c_char_p, C.POINTER(SolveOpts), C.POINTER(Result)]

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -34,6 +35,7 @@ struct KNode {
     std::vector<int32_t> idx; std::vector<int8_t> val;      // fixed decisions, ascending item index
     double bound = 0; Relax self;                          // own relaxation (bound == self.profit)
     Relax child[2];                                        // cached children (x=0, x=1)
+    Relax gchild[2][2];                                    // cached children of child v (lpx_knapsack_relax_batch2)
 };
 using NodeP = std::unique_ptr<KNode>;
 
@@ -73,7 +75,8 @@ struct Search {
     std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
 
     // evaluates `jobs` = (node, fixed item, value) in one launch
-    struct Job { KNode* node; int item; int v; Relax* out; };
+    struct Job { KNode* node; int item; int v; Relax* out; Relax* gout; };   // gout: two slots for the job's own children, or null
+    bool depth2 = false;                                 // one launch also evaluates each job's two children
     void run_jobs(std::vector<Job>& jobs)
     {
         if (jobs.empty()) return;
@@ -89,15 +92,25 @@ struct Search {
             if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
             off[j + 1] = (int32_t)fidx.size();
         }
-        std::vector<double> p(jobs.size()), w(jobs.size()), fv(jobs.size()); std::vector<int32_t> fr(jobs.size());
+        const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
+        std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
         if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
         int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                            : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
+               : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                        : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         ++launches;
         for (size_t j = 0; j < jobs.size(); ++j) {
             Relax& r = *jobs[j].out;
-            r.profit = p[j]; r.weight = w[j]; r.frac = fr[j]; r.fracval = fv[j]; r.valid = true;
+            r.profit = p[st * j]; r.weight = w[st * j]; r.frac = fr[st * j]; r.fracval = fv[st * j]; r.valid = true;
+            if (depth2 && jobs[j].gout) {
+                for (int c = 0; c < 2; ++c) {
+                    Relax& g = jobs[j].gout[c];
+                    const size_t o = st * j + 1 + c;
+                    g.valid = fr[o] != -2;
+                    if (g.valid) { g.profit = p[o]; g.weight = w[o]; g.frac = fr[o]; g.fracval = fv[o]; }
+                }
+            }
         }
     }
 
@@ -148,6 +161,7 @@ struct Search {
                 }
                 if (!placed) { ch->idx.push_back(item); ch->val.push_back((int8_t)v); }
                 ch->bound = r.profit; ch->self = r;
+                ch->child[0] = node->gchild[v][0]; ch->child[1] = node->gchild[v][1];   // already evaluated with the parent's launch
                 pq.push(ch.get());
                 store.push_back(std::move(ch));
                 max_heap = std::max<int64_t>(max_heap, (int64_t)pq.d.size());
@@ -179,15 +193,15 @@ struct Search {
         if (!node->child[0].valid || !node->child[1].valid) {
             // one launch: this node's children plus those of the nodes near the top of the heap
             std::vector<Job> jobs;
-            jobs.push_back({node, item, 0, &node->child[0]});
-            jobs.push_back({node, item, 1, &node->child[1]});
+            jobs.push_back({node, item, 0, &node->child[0], node->gchild[0]});
+            jobs.push_back({node, item, 1, &node->child[1], node->gchild[1]});
             const size_t lim = std::min<size_t>(pq.d.size(), (size_t)spec);
             for (size_t i = 0; i < lim; ++i) {
                 KNode* o = pq.d[i];
                 if (o->child[0].valid || o->self.frac < 0 || o->bound <= best + EPS) continue;
                 const int it = order[o->self.frac];
-                jobs.push_back({o, it, 0, &o->child[0]});
-                jobs.push_back({o, it, 1, &o->child[1]});
+                jobs.push_back({o, it, 0, &o->child[0], o->gchild[0]});
+                jobs.push_back({o, it, 1, &o->child[1], o->gchild[1]});
             }
             run_jobs(jobs);
         }
@@ -233,11 +247,15 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     S.k = kh;
     S.bestX.assign(n, 0);
     S.spec = opt.concurrent_nodes > 1 ? opt.concurrent_nodes : 64;
+    {   // every launch also evaluates the children of the nodes it evaluates (LPX_KNAP_DEPTH2=0: off)
+        const char* e = std::getenv("LPX_KNAP_DEPTH2");
+        S.depth2 = !S.test_relax && kh && lpx_knapsack_has_prefix(kh) && !(e && e[0] == '0');
+    }
 
     std::vector<NodeP> store;
     Heap pq;
     NodeP root(new KNode());                                                // :102-113
-    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self}}; S.run_jobs(j); S.relaxations++; }
+    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self, root->child}}; S.run_jobs(j); S.relaxations++; }
     root->bound = root->self.profit;
     pq.push(root.get()); store.push_back(std::move(root));
     S.max_heap = 1;

@@ -149,6 +149,11 @@ struct KnPrefix { const double* PW; const double* PP; };
 
 static constexpr int KP_CACHE = 4;        // fixed entries cached in registers per lane (depth <= 256)
 
+// DEPTH2: after the node itself (slot 3k) the wave also evaluates the node's two children, i.e. the node with its
+// fractional item additionally fixed to 0 (slot 3k+1) and to 1 (slot 3k+2) -- the very relaxations the best-first
+// loop asks for when it pops this node next, so the host finds them cached and launches half as often.  The extra
+// decision is one more fixed entry (its ratio position is the node's `frac`, weight / profit from the sorted arrays).
+template <bool DEPTH2>
 __global__ __launch_bounds__(256) void knap_relax_prefix(KnParams P, KnPrefix X)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -172,51 +177,68 @@ __global__ __launch_bounds__(256) void knap_relax_prefix(KnParams P, KnPrefix X)
         const int i = P.fidx[f0 + e];
         if (P.fval[f0 + e] == 1) { w1 += P.w0[i]; p1 += P.p0[i]; }
     }
-    const double W1 = wave_sum_f64(w1), P1 = wave_sum_f64(p1);     // :442-452 (exact for integer data)
-    if (W1 > P.cap + KEPS) {                                        // :455-456
-        if (lane == 0) { P.out_profit[node] = P1; P.out_weight[node] = W1; P.out_frac[node] = -1; P.out_fracval[node] = 0.0; }
-        return;
-    }
-    // fixed weight / profit in front of position t
-    auto fixed_before = [&](int t, double& fw, double& fp) {
-        double a = 0.0, b = 0.0;
+    const double W1n = wave_sum_f64(w1), P1n = wave_sum_f64(p1);   // :442-452 (exact for integer data)
+
+    // one relaxation: the node's fixed list plus (optionally) the item at ratio position xpos fixed to xval
+    auto solve = [&](int xpos, int xval, double xw, double xp, int slot) {
+        const double W1 = W1n + (xval == 1 ? xw : 0.0), P1 = P1n + (xval == 1 ? xp : 0.0);
+        if (W1 > P.cap + KEPS) {                                        // :455-456
+            if (lane == 0) { P.out_profit[slot] = P1; P.out_weight[slot] = W1; P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0; }
+            return -1;
+        }
+        // fixed weight / profit in front of position t
+        auto fixed_before = [&](int t, double& fw, double& fp) {
+            double a = 0.0, b = 0.0;
 #pragma unroll
-        for (int k = 0; k < KP_CACHE; ++k) if (cpos[k] < t) { a += cw[k]; b += cp[k]; }
-        for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {
-            const int i = P.fidx[f0 + e];
-            if (P.pos[i] < t) { a += P.w0[i]; b += P.p0[i]; }
+            for (int k = 0; k < KP_CACHE; ++k) if (cpos[k] < t) { a += cw[k]; b += cp[k]; }
+            for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {
+                const int i = P.fidx[f0 + e];
+                if (P.pos[i] < t) { a += P.w0[i]; b += P.p0[i]; }
+            }
+            fw = wave_sum_f64(a); fp = wave_sum_f64(b);
+            if (xpos < t) { fw += xw; fp += xp; }
+        };
+        int lo = 1, hi = n + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            double fw, fp;
+            fixed_before(mid, fw, fp);
+            if (W1 + (X.PW[mid] - fw) > P.cap + KEPS) hi = mid; else lo = mid + 1;
         }
-        fw = wave_sum_f64(a); fp = wave_sum_f64(b);
-    };
-    int lo = 1, hi = n + 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
         double fw, fp;
-        fixed_before(mid, fw, fp);
-        if (W1 + (X.PW[mid] - fw) > P.cap + KEPS) hi = mid; else lo = mid + 1;
-    }
-    double fw, fp;
-    if (lo == n + 1) {                                              // everything undecided fits
-        fixed_before(n, fw, fp);
-        if (lane == 0) {
-            P.out_profit[node] = P1 + (X.PP[n] - fp); P.out_weight[node] = W1 + (X.PW[n] - fw);
-            P.out_frac[node] = -1; P.out_fracval[node] = 0.0;
+        if (lo == n + 1) {                                              // everything undecided fits
+            fixed_before(n, fw, fp);
+            if (lane == 0) {
+                P.out_profit[slot] = P1 + (X.PP[n] - fp); P.out_weight[slot] = W1 + (X.PW[n] - fw);
+                P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0;
+            }
+            return -1;
         }
+        const int j = lo - 1;                                           // first undecided item that does not fit
+        fixed_before(j, fw, fp);
+        double w = W1 + (X.PW[j] - fw), p = P1 + (X.PP[j] - fp);
+        int frac = -1; double fv = 0.0;
+        const double wi = P.ws[j];
+        const double remain = P.cap - w;
+        if (remain > KEPS && wi > KEPS) {                               // :476-484
+            fv = remain / wi;
+            p += P.ps[j] * fv;
+            w += wi * fv;
+            frac = j;
+        }
+        if (lane == 0) { P.out_profit[slot] = p; P.out_weight[slot] = w; P.out_frac[slot] = frac; P.out_fracval[slot] = fv; }
+        return frac;
+    };
+
+    if (!DEPTH2) { solve(INT_MAX, 0, 0.0, 0.0, node); return; }
+    const int frac = solve(INT_MAX, 0, 0.0, 0.0, 3 * node);
+    if (frac < 0) {                                                     // no fractional item: nothing to branch on
+        if (lane == 0) { P.out_frac[3 * node + 1] = -2; P.out_frac[3 * node + 2] = -2; }
         return;
     }
-    const int j = lo - 1;                                           // first undecided item that does not fit
-    fixed_before(j, fw, fp);
-    double w = W1 + (X.PW[j] - fw), p = P1 + (X.PP[j] - fp);
-    int frac = -1; double fv = 0.0;
-    const double wi = P.ws[j];
-    const double remain = P.cap - w;
-    if (remain > KEPS && wi > KEPS) {                               // :476-484
-        fv = remain / wi;
-        p += P.ps[j] * fv;
-        w += wi * fv;
-        frac = j;
-    }
-    if (lane == 0) { P.out_profit[node] = p; P.out_weight[node] = w; P.out_frac[node] = frac; P.out_fracval[node] = fv; }
+    const double xw = P.ws[frac], xp = P.ps[frac];
+    solve(frac, 0, xw, xp, 3 * node + 1);
+    solve(frac, 1, xw, xp, 3 * node + 2);
 }
 
 }  // namespace lpx
@@ -308,20 +330,21 @@ int lpx_knapsack_order(lpx_knapsack* k, int32_t* order)
     return 0;
 }
 
-int lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
-                             const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
-                             double* frac_val)
+static int relax_batch_impl(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
+                            const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                            double* frac_val, bool depth2)
 {
     if (!k || count < 0 || !off) { set_error("lpx_knapsack_relax_batch: bad argument"); return LPX_EINVAL; }
     if (count == 0) return 0;
+    const int nout = depth2 ? 3 * count : count;
     const int nfix = off[count];
     for (int e = 0; e < nfix; ++e)
         if (fix_idx[e] < 0 || fix_idx[e] >= k->n) { set_error("lpx_knapsack_relax_batch: fixed index outside [0,n)"); return LPX_EINVAL; }
     auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     const size_t o_off = 0, o_fidx = up8(sizeof(int32_t) * (count + 1)), o_fval = o_fidx + up8(sizeof(int32_t) * (size_t)(nfix > 0 ? nfix : 1));
     const size_t in_bytes = o_fval + up8((size_t)(nfix > 0 ? nfix : 1));
-    const size_t o_p = 0, o_w = sizeof(double) * count, o_fv = 2 * sizeof(double) * count, o_fr = 3 * sizeof(double) * count;
-    const size_t out_bytes = o_fr + up8(sizeof(int32_t) * count);
+    const size_t o_p = 0, o_w = sizeof(double) * nout, o_fv = 2 * sizeof(double) * nout, o_fr = 3 * sizeof(double) * nout;
+    const size_t out_bytes = o_fr + up8(sizeof(int32_t) * nout);
     if (in_bytes > k->in_cap) {
         hipFree(k->d_in); if (k->h_in) hipHostFree(k->h_in);
         k->d_in = nullptr; k->h_in = nullptr; k->in_cap = 0;
@@ -353,7 +376,10 @@ int lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, con
     static const bool force_scan = [] { const char* e = std::getenv("LPX_KNAP_SCAN"); return e && e[0] == '1'; }();
     if (k->prefix_ok && !force_scan) {
         KnPrefix X; X.PW = k->PW; X.PP = k->PP;
-        hipLaunchKernelGGL(knap_relax_prefix, dim3((count + 3) / 4), dim3(256), 0, s, P, X);
+        if (depth2) hipLaunchKernelGGL(knap_relax_prefix<true>, dim3((count + 3) / 4), dim3(256), 0, s, P, X);
+        else hipLaunchKernelGGL(knap_relax_prefix<false>, dim3((count + 3) / 4), dim3(256), 0, s, P, X);
+    } else if (depth2) {
+        set_error("lpx_knapsack_relax_batch2 needs the prefix-sum path (non-negative weights)"); return LPX_EINVAL;
     } else {
         const size_t dyn = sizeof(unsigned int) * ((k->n + 31) / 32);
         hipLaunchKernelGGL(knap_relax_batch, dim3(count), dim3(KN_NT), dyn, s, P);
@@ -361,11 +387,28 @@ int lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, con
     LPX_HIP_TRY(hipGetLastError());
     LPX_HIP_TRY(hipMemcpyAsync(k->h_out, k->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     LPX_HIP_TRY(hipStreamSynchronize(s));
-    if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * count);
-    if (weight) std::memcpy(weight, k->h_out + o_w, sizeof(double) * count);
-    if (frac_val) std::memcpy(frac_val, k->h_out + o_fv, sizeof(double) * count);
-    if (frac_idx) std::memcpy(frac_idx, k->h_out + o_fr, sizeof(int32_t) * count);
+    if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * nout);
+    if (weight) std::memcpy(weight, k->h_out + o_w, sizeof(double) * nout);
+    if (frac_val) std::memcpy(frac_val, k->h_out + o_fv, sizeof(double) * nout);
+    if (frac_idx) std::memcpy(frac_idx, k->h_out + o_fr, sizeof(int32_t) * nout);
     return 0;
 }
+
+int lpx_knapsack_relax_batch(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
+                             const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                             double* frac_val)
+{
+    return relax_batch_impl(k, count, off, fix_idx, fix_val, profit, weight, frac_idx, frac_val, false);
+}
+
+int lpx_knapsack_relax_batch2(lpx_knapsack* k, int count, const int32_t* off, const int32_t* fix_idx,
+                              const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
+                              double* frac_val)
+{
+    if (k && !k->prefix_ok) { set_error("lpx_knapsack_relax_batch2 needs the prefix-sum path (non-negative weights)"); return LPX_EINVAL; }
+    return relax_batch_impl(k, count, off, fix_idx, fix_val, profit, weight, frac_idx, frac_val, true);
+}
+
+int lpx_knapsack_has_prefix(lpx_knapsack* k) { return k && k->prefix_ok ? 1 : 0; }
 
 }  // extern "C"

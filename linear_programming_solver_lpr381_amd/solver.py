@@ -349,6 +349,28 @@ class DeviceKnapsack:
         _lib.check(lib().lpx_knapsack_order(self._h, o.ctypes.data_as(_lib.ip)))
         return o
 
+    def relax_batch2(self, nodes):
+        """lpx_knapsack_relax_batch2: like relax_batch, and for every node also its two children (the node with its
+        fractional item fixed to 0 / 1).  Returns arrays of shape (len(nodes), 3): column 0 the node, 1 and 2 the
+        children; frac == -2 marks children that do not exist (no fractional item)."""
+        off = [0]
+        fidx, fval = [], []
+        for nd in nodes:
+            for i in sorted(nd):
+                fidx.append(i)
+                fval.append(nd[i])
+            off.append(len(fidx))
+        off = np.asarray(off, np.int32)
+        fi = np.asarray(fidx if fidx else [0], np.int32)
+        fv = np.asarray(fval if fval else [0], np.int8)
+        k = len(nodes)
+        p = np.zeros(3 * k); w = np.zeros(3 * k); fr = np.zeros(3 * k, np.int32); fx = np.zeros(3 * k)
+        _lib.check(lib().lpx_knapsack_relax_batch2(self._h, k, off.ctypes.data_as(_lib.ip), fi.ctypes.data_as(_lib.ip),
+                                                   fv.ctypes.data_as(C.POINTER(C.c_int8)), p.ctypes.data_as(_lib.dp),
+                                                   w.ctypes.data_as(_lib.dp), fr.ctypes.data_as(_lib.ip),
+                                                   fx.ctypes.data_as(_lib.dp)))
+        return p.reshape(k, 3), w.reshape(k, 3), fr.reshape(k, 3), fx.reshape(k, 3)
+
     def relax_batch(self, nodes):
         """nodes: list of dict {item_index: 0/1}. Returns (profit, weight, frac_sorted_idx, frac_value)."""
         off = [0]

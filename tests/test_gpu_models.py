@@ -196,6 +196,46 @@ def test_knapsack_relax_batch_vs_oracle(gpu, oracle):
         dk.close()
 
 
+def test_knapsack_relax_batch2_children_vs_oracle(gpu, oracle):
+    """lpx_knapsack_relax_batch2: slot 0 = the node, slots 1 / 2 = the node with its fractional item fixed to 0 / 1
+    (what the best-first loop asks for when it pops the node, BranchAndBoundKnapsack.cs:180,207-209,267-269)."""
+    g = np.random.default_rng(31)
+    for n in (6, 41, 700, 5000):
+        w = g.integers(1, 1001, size=n).astype(float)
+        p = w + g.integers(0, 101, size=n)
+        cap = float(np.floor(0.5 * w.sum()))
+        dk = gpu.DeviceKnapsack(p, w, cap)
+        order = oracle.knapsack_order(p, w)
+        nodes = [{}]
+        for t in range(40):
+            k = int(g.integers(0, min(n, 300)))              # deeper than the 256 register-cached entries too
+            idx = g.choice(n, size=k, replace=False)
+            nodes.append({int(i): int(g.integers(0, 2)) for i in idx})
+        nodes.append({int(i): 1 for i in range(n)})          # overflow: no children
+        nodes.append({int(i): 0 for i in range(n)})          # nothing left: no fractional item
+        P, W, F, X = dk.relax_batch2(nodes)
+        P1, W1, F1, X1 = dk.relax_batch(nodes)
+        assert (P[:, 0].tolist(), W[:, 0].tolist(), F[:, 0].tolist(), X[:, 0].tolist()) == (P1.tolist(), W1.tolist(), F1.tolist(), X1.tolist())
+        seen_children = 0
+        for j, nd in enumerate(nodes):
+            if F[j, 0] < 0:
+                assert F[j, 1] == -2 and F[j, 2] == -2, (n, j)
+                continue
+            item = int(order[F[j, 0]])
+            for v in (0, 1):
+                a = -np.ones(n, np.int32)
+                for i, val in nd.items():
+                    a[i] = val
+                a[item] = v
+                rp, rw, rf, rx = oracle.knapsack_relax(p, w, cap, order, a, want_vector=True)
+                assert (P[j, 1 + v], W[j, 1 + v], F[j, 1 + v]) == (rp, rw, rf), (n, j, v)
+                if rf >= 0:
+                    assert X[j, 1 + v] == rx[order[rf]]
+                seen_children += 1
+        assert seen_children >= 40
+        dk.close()
+
+
 def test_kat8_knapsack_and_oracle_parity(gpu, oracle):
     k = KATS["kat8_knapsack"]
     P, C_, S, R = gpu.LPProblem, gpu.Constraint, gpu.Sense, gpu.Rel
