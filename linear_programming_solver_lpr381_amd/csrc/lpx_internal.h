@@ -99,6 +99,9 @@ hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int
 void set_error(const std::string& msg);
 int ensure_device();                // binds a device and sets kernel attributes once
 double now_ms();
+// hipStreamCreate costs 4-9 ms on this stack (an HSA queue each) while the hardware runs a handful of queues anyway:
+// handles borrow one of a few process-wide streams (round robin) and never destroy them.
+hipStream_t borrow_stream();
 
 // Generic device-resident loop: enqueue `batch` iterations (eager, hipGraph replay, or event-
 // bracketed), poll the device state once per batch, fire pivot callbacks from the trace.

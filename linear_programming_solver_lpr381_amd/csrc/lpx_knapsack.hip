@@ -273,7 +273,6 @@ void lpx_knapsack_destroy(lpx_knapsack* k)
     hipFree(k->d_in); hipFree(k->d_out);
     if (k->h_in) hipHostFree(k->h_in);
     if (k->h_out) hipHostFree(k->h_out);
-    if (k->stream) hipStreamDestroy(k->stream);
     delete k;
 }
 
@@ -317,7 +316,7 @@ int lpx_knapsack_create(const double* profit, const double* weight, int n, doubl
     for (int s = 0; s < n; ++s) { PW[s + 1] = PW[s] + ws[s]; PP[s + 1] = PP[s] + ps[s]; if (!(ws[s] >= 0.0)) nonneg = false; }
     k->prefix_ok = nonneg;
     up((void**)&k->PW, PW.data(), sizeof(double) * (n + 1)); up((void**)&k->PP, PP.data(), sizeof(double) * (n + 1));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && (k->stream = borrow_stream()) == nullptr) e = hipErrorUnknown;
     if (e != hipSuccess) { set_error(std::string("lpx_knapsack_create: ") + hipGetErrorString(e)); lpx_knapsack_destroy(k); return LPX_EDEVICE; }
     *out = k;
     return 0;

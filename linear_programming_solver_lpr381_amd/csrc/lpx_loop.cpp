@@ -36,6 +36,20 @@ int ensure_device()
     return 0;
 }
 
+hipStream_t borrow_stream()
+{
+    static constexpr int kStreams = 8;
+    static hipStream_t pool[kStreams];
+    static int made = 0, next = 0;
+    if (made < kStreams) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return made ? pool[next++ % made] : nullptr;
+        pool[made] = s;
+        return pool[made++];
+    }
+    return pool[next++ % kStreams];
+}
+
 double now_ms()
 {
     using namespace std::chrono;

@@ -324,7 +324,6 @@ struct InvWork {
         if (gexec) hipGraphExecDestroy(gexec);
         hipFree(A); hipFree(prow); hipFree(pcol); hipFree(st);
         if (hst) hipHostFree(hst);
-        if (stream) hipStreamDestroy(stream);
     }
 };
 
@@ -336,7 +335,7 @@ int inv_alloc(InvWork& w, int n)
     LPX_HIP_TRY(hipMalloc((void**)&w.pcol, sizeof(double) * n));
     LPX_HIP_TRY(hipMalloc((void**)&w.st, sizeof(DevState)));
     LPX_HIP_TRY(hipHostMalloc((void**)&w.hst, sizeof(DevState)));
-    LPX_HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    if ((w.stream = borrow_stream()) == nullptr) { set_error("no stream"); return LPX_EDEVICE; }
     LPX_HIP_TRY(hipMemsetAsync(w.prow, 0, sizeof(double) * w.ld, w.stream));
     return 0;
 }
@@ -420,7 +419,6 @@ void lpx_revised_destroy(lpx_revised* r)
     hipFree(r->st); hipFree(r->b); hipFree(r->Mb);
     delete r->inv;
     if (r->hst) hipHostFree(r->hst);
-    if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }
 
@@ -450,7 +448,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     RALLOC(r->b, sizeof(double) * m);
 #undef RALLOC
     if (hipHostMalloc((void**)&r->hst, sizeof(DevState)) != hipSuccess ||
-        hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+        (r->stream = borrow_stream()) == nullptr) {
         set_error("pinned state / stream creation failed"); hipFree(Atmp); lpx_revised_destroy(r); return LPX_EDEVICE;
     }
     hipStream_t s = r->stream;

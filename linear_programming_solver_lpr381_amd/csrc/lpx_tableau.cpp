@@ -153,7 +153,7 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
         t->shape = (int32_t*)p; p += sz[k++];
     }
     if (hipHostMalloc((void**)&t->hslab, 256 + sizeof(int32_t) * 2) != hipSuccess ||
-        hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+        (t->stream = borrow_stream()) == nullptr) {
         set_error("host-pinned state / stream creation failed");
         lpx_tableau_destroy(t);
         return LPX_EDEVICE;
@@ -181,8 +181,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis);
     if (t->hslab) hipHostFree(t->hslab);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
-    if (t->stream) hipStreamDestroy(t->stream);
-    delete t;
+    delete t;                       // the stream is borrowed (borrow_stream), not owned
 }
 
 int lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld)
