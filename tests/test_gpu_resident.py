@@ -219,3 +219,27 @@ def test_resident_group_multi_run_matches_streaming_batch(oracle):
     env = dict(os.environ, LPX_RESIDENT_GROUP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("cleanup,guard", [(0, 100), (1, 10000)])
+def test_dual_resident_and_streaming_paths_agree_with_the_oracle(gpu, oracle, cleanup, guard):
+    """lpx_dual_run picks the resident group kernel by itself; the streaming dual kernels stay the path for large
+    tableaux and for B&B batches -- both must give the oracle's bits (faithful guard 100 and repaired mode)."""
+    g = np.random.default_rng(17)
+    for trial in range(6):
+        m, n = int(g.integers(12, 90)), int(g.integers(20, 120))
+        c, A, b = synth.dense_lp(m, n, seed=300 + trial)
+        b = b.copy(); b[: 1 + trial % 5] *= -0.04                  # negative right-hand sides, as a >= row leaves them
+        if trial % 2:
+            c = -c                                                 # dual feasible from the start: straight into the dual loop
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref, nf = oracle.dual_tableau(Tr, br, fdf_guard=guard, cleanup=cleanup)
+        for res in (1, -1):
+            with gpu.DeviceTableau.from_host(T, basis) as dt:
+                status, st = dt.dual_run(fdf_guard=guard, cleanup=cleanup, resident=res)
+                Tg, bg = dt.download()
+                assert status == st_ref, (trial, res)
+                assert dt.trace().tolist() == tr_ref.tolist() and bg.tolist() == br.tolist()
+                assert np.array_equal(_bits(Tg), _bits(Tr))
+                assert st["fdf_pivots"] == nf and (st["launches"] <= 2) == (res == 1)
