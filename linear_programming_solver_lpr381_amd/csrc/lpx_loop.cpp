@@ -94,7 +94,7 @@ int LoopRun::begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o
     if (o_.profile && batch_ > 256) batch_ = 256;
     graph_ = o_.use_graph && !o_.profile;
     *c_.hst = init;                                 // pinned staging: safe for the async copy below
-    if (c.start_iter > 0) { c_.hst->iter = c.start_iter; c_.hst->primal_count = (init.phase == 2) ? c.start_iter : 0; }
+    if (c.start_iter > 0 && init.iter == 0) { c_.hst->iter = c.start_iter; c_.hst->primal_count = (init.phase == 2) ? c.start_iter : 0; }
     LPX_HIP_TRY(hipMemcpyAsync(c_.st, c_.hst, sizeof(DevState), hipMemcpyHostToDevice, c_.stream));
     LPX_HIP_TRY(hipStreamSynchronize(c_.stream));
     if (o_.profile) {

@@ -7,9 +7,10 @@
 //   * the full state machine of the dual path (lpx_select_body in lpx_kernels.hip): ForceDualFeasibility
 //     (Models/DualSimplex.cs:195-228), the dual loop (:36-113) and the repaired mode's primal clean-up, with the
 //     primal loop (Models/PrimalSimplex.cs:92-124) as the special case "phase 2 from the start".
-// Exchange 1 carries TWO values per row: the ratio rhs_i / T[i, q] for the entering column the primal-like phases
-// will use (every workgroup knows q from its objective replica; +inf when ineligible), and rhs_i for the dual loop's leaving row
-// (most negative RHS, first index).  In the dual loop the entering column is chosen by the OWNER of row r -- it has
+// Exchange 1 carries ONE value per row, chosen by the phase the next decision is in: the ratio rhs_i / T[i, q] for the
+// entering column of the primal-like phases (every workgroup knows q from its objective replica; +inf when ineligible),
+// or rhs_i for the dual loop's leaving row (most negative RHS, first index).  A phase hop that needs the other kind
+// costs one exchange round without a pivot (once or twice per LP).  In the dual loop the entering column is chosen by the OWNER of row r -- it has
 // the row and the objective replica, so the column ratio scan of :79-91 is local -- and travels as a header
 // granule behind the normalised row.  Control state (phase, counters) is replicated: every workgroup of a group
 // sees the same gathered data and takes the same decisions.
@@ -19,7 +20,7 @@
 
 namespace lpx {
 
-struct ResGroupParams { const ResNode* nodes; int chunk; };
+struct ResGroupParams { const ResNode* nodes; int chunk; int mute; };   // mute: diagnostic, LPX_RESIDENT_TEST_MUTE
 
 #ifdef LPX_STAMPS
 #define RG_T0 unsigned long long rg_prev_ = __builtin_amdgcn_s_memtime();
@@ -52,26 +53,28 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     const double eps = N.eps;
     DevState* st = N.st;
     if (st->status != LPX_RUNNING) return;
+    if ((GP.mute == 1 || (GP.mute == 2 && st->iter > 0)) && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) return;   // plays dead
     const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
-    const int ld = P.ld, C = P.C, m = P.R - 1, rhsc = C - 1;
+    const int C = P.C, m = P.R - 1, rhsc = C - 1;
     const int rpw = (m + G - 1) / G;
     const int row0 = w * rpw;
     const int nloc = max(0, min(rpw, m - row0));
     const int mp = (m + 1) & ~1;
+    const int gld = P.ld;                       // leading dimension in HBM (padded to 16 doubles)
+    const int ld = (C + 1) & ~1;                // in LDS: just even, so that a fourth 8 MB node fits on the chip
     double* tile = rs_lds;                      // [rpw][ld]
     double* obj = tile + (size_t)rpw * ld;      // [ld]
     double* prow = obj + ld;                    // [ld]
-    double* colA = prow + ld;                   // [m]  gathered ratios rhs_i / a_i (+inf when a_i <= eps)
-    double* colB = colA + mp;                   // [m]  gathered rhs_i
-    double* fac = colB + mp;                    // [rpw+1]
+    double* col = prow + ld;                    // [m]  gathered per-row values: ratios (phases 0 / 2) or rhs (phase 1)
+    double* fac = col + mp;                     // [rpw+1]
 
     for (int i = 0; i < nloc; ++i) {
-        const double* src = P.T + (size_t)(row0 + i) * ld;
+        const double* src = P.T + (size_t)(row0 + i) * gld;
         for (int j = 2 * t; j < ld; j += 2 * RS_NT)
             *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = *reinterpret_cast<const double2*>(src + j);
     }
     {
-        const double* src = P.T + (size_t)m * ld;
+        const double* src = P.T + (size_t)m * gld;
         for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
             *reinterpret_cast<double2*>(obj + j) = *reinterpret_cast<const double2*>(src + j);
             *reinterpret_cast<double2*>(prow + j) = make_double2(0.0, 0.0);
@@ -98,12 +101,14 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         int t = t_outer;
         asm volatile("" : "+v"(t));
         if (publish_now) {
+            // ForceDualFeasibility ends by itself when its guard is used up or no column is left (:202,:206-208): the hop
+            // to the dual loop is taken here already, so that the rows publish what that loop needs (their rhs).
+            if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
             if (t < nloc) {
-                u64* g = P.xr + 4 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t);
                 const double rhs0 = tile[(size_t)t * ld + rhsc];
-                const double a0 = qc >= 0 ? tile[(size_t)t * ld + qc] : 0.0;
-                rs_publish(g, a0 > eps ? rhs0 / a0 : __builtin_inf(), gen + 1u);        // ratio of :229-233
-                rs_publish(g + 2, rhs0, gen + 1u);
+                double v = rhs0;
+                if (phase != 1) { const double a0 = qc >= 0 ? tile[(size_t)t * ld + qc] : 0.0; v = a0 > eps ? rhs0 / a0 : __builtin_inf(); }   // :229-233
+                rs_publish(P.xr + 2 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t), v, gen + 1u);
             }
             publish_now = false;
         }
@@ -111,13 +116,13 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         const int par = (int)(gen & 1u);
         // ---- exchange 1: (a_i, rhs_i) of every row ------------------------------------------------------------
         int fail = 0;
-        for (int base = t; base < m; base += RS_NT * 2) {
-            int idx[RS_FETCH]; double val[RS_FETCH];
-            const int i0 = base, i1 = base + RS_NT;
-            idx[0] = 2 * i0; idx[1] = 2 * i0 + 1; idx[2] = 2 * (i1 < m ? i1 : i0); idx[3] = idx[2] + 1;
-            if (!rs_gather(P.xr + 4 * (size_t)par * P.mcap, idx, i1 < m ? 4 : 2, gen, val)) fail = 1;
-            colA[i0] = val[0]; colB[i0] = val[1];
-            if (i1 < m) { colA[i1] = val[2]; colB[i1] = val[3]; }
+        for (int base = t; base < m; base += RS_NT * RS_FETCH) {
+            int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < RS_FETCH; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < m) cnt = u + 1; }
+            if (!rs_gather(P.xr + 2 * (size_t)par * P.mcap, idx, cnt, gen, val)) fail = 1;
+#pragma unroll
+            for (int u = 0; u < RS_FETCH; ++u) if (u < cnt) col[idx[u]] = val[u];
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
         RG_T(1);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0 && !republish; ++hop) {
             if (phase == 1) {                                                   // dual loop, Models/DualSimplex.cs:36-113
                 if (dual_iter >= N.max_iter) { final_status = LPX_ITER_LIMIT; break; }
-                r = first4_first_min_below(colB, m, eps, s_v, s_i);             // most negative RHS, first index (:45-55)
+                r = first4_first_min_below(col, m, eps, s_v, s_i);              // most negative RHS, first index (:45-55)
                 if (r < 0) {
                     if (N.cleanup) {
                         const int qe = first4_first_min_below(obj, rhsc, eps, s_v, s_i);
@@ -140,12 +145,13 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
                 q = -2;                                                         // chosen by the owner of row r below
             } else {
                 // ForceDualFeasibility (phase 0, :195-228) and the primal loop (phase 2, PrimalSimplex.cs:92-124)
-                if (phase == 0 && fdf_count >= N.fdf_guard) { phase = 1; continue; }
+                // (a hop 0 -> 1 needs the rows' rhs instead of their ratios: one exchange round without a pivot)
+                if (phase == 0 && fdf_count >= N.fdf_guard) { phase = 1; qc = -1; republish = true; break; }
                 if (phase == 2 && primal_count >= N.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
                 q = qc;
-                if (q < 0) { if (phase == 0) { phase = 1; continue; } final_status = LPX_OPTIMAL; break; }
-                r = rs_hysteresis(m, phase == 0 ? N.tol_fdf : N.tol_primal, colA, s_v, s_i, &s_out);
-                if (r < 0) { q = -1; if (phase == 0) { phase = 1; continue; } final_status = LPX_UNBOUNDED; break; }
+                if (q < 0) { if (phase == 0) { phase = 1; qc = -1; republish = true; break; } final_status = LPX_OPTIMAL; break; }
+                r = rs_hysteresis(m, phase == 0 ? N.tol_fdf : N.tol_primal, col, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; if (phase == 0) { phase = 1; qc = -1; republish = true; break; } final_status = LPX_UNBOUNDED; break; }
             }
         }
         if (republish) { publish_now = true; continue; }                        // one exchange round without a pivot
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         RG_T(2);
         // ---- exchange 2: the owner normalises row r (and, in the dual loop, chooses the entering column) ---------
         const int owner = r / rpw, rl = r - owner * rpw;
-        u64* xp = P.xp + 2 * (size_t)par * (ld + 8);
+        u64* xp = P.xp + 2 * (size_t)par * (gld + 8);
         if (w == owner) {
             double* prw = tile + (size_t)rl * ld;
             if (phase == 1) {                                                   // entering column of the dual loop, :79-91
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             }
             if (phase == 1) {
                 __syncthreads();
-                if (t == 0) rs_publish(xp + 2 * (size_t)ld, (double)q, gen);    // header {q} behind the row
+                if (t == 0) rs_publish(xp + 2 * (size_t)gld, (double)q, gen);   // header {q} behind the row
             }
         } else if (phase != 1) {
             // q is known (it came from the objective replica): exactly the consumer side of lpx_resident_primal --
@@ -212,13 +218,13 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
                 for (int u = 0; u < 3; ++u) { idx[u] = base + u * RS_NT; if (idx[u] < C) cnt = u + 1; }
                 unsigned pend = (1u << cnt) - 1u;
                 if (first) {
-                    idx[cnt] = ld;                                              // the header rides in the spare slot
+                    idx[cnt] = gld;                                             // the header rides in the spare slot
                     unsigned p2 = pend | (1u << cnt);
                     rs_gather(xp, idx, cnt + 1, gen, val, 1u, &p2);
                     if (!((p2 >> cnt) & 1u)) { hq = val[cnt]; hpend = 0u; }
                     pend = p2 & ((1u << cnt) - 1u);
                     if (hpend) {
-                        int hidx[RS_FETCH] = {ld, ld, ld, ld}; double hval[RS_FETCH];
+                        int hidx[RS_FETCH] = {gld, gld, gld, gld}; double hval[RS_FETCH];
                         if (!rs_gather(xp, hidx, 1, gen, hval)) fail = 1;
                         hq = hval[0]; hpend = 0u;
                     }
@@ -265,6 +271,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         RG_T(4);
         // ---- lookahead: next round's (a, rhs) leave before the bulk of the update ---------------------------------
         if (k + 1 < GP.chunk) {
+            // the hop out of ForceDualFeasibility that is already certain (:202,:206-208) is taken before publishing
+            if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
             if (t < nloc) {
                 double a = 0.0, rhs;
                 if (t == skip) { if (qc >= 0) a = prow[qc]; rhs = prow[rhsc]; }
@@ -273,9 +281,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
                     if (qc >= 0) { const double prod = f * prow[qc]; a = tile[(size_t)t * ld + qc] - prod; }
                     const double prod2 = f * prow[rhsc]; rhs = tile[(size_t)t * ld + rhsc] - prod2;
                 }
-                u64* g = P.xr + 4 * ((size_t)(par ^ 1) * P.mcap + row0 + t);
-                rs_publish(g, a > eps ? rhs / a : __builtin_inf(), gen + 1u);
-                rs_publish(g + 2, rhs, gen + 1u);
+                const double v = (phase == 1) ? rhs : (a > eps ? rhs / a : __builtin_inf());
+                rs_publish(P.xr + 2 * ((size_t)(par ^ 1) * P.mcap + row0 + t), v, gen + 1u);
             }
         }
         __syncthreads();                        // the lookahead read columns qc and rhs before anyone rewrites them
@@ -301,12 +308,12 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         return;
     }
     for (int i = 0; i < nloc; ++i) {
-        double* dst = P.T + (size_t)(row0 + i) * ld;
+        double* dst = P.T + (size_t)(row0 + i) * gld;
         for (int j = 2 * t; j < ld; j += 2 * RS_NT)
             *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(tile + (size_t)i * ld + j);
     }
     if (w == 0) {
-        double* dst = P.T + (size_t)m * ld;
+        double* dst = P.T + (size_t)m * gld;
         for (int j = 2 * t; j < ld; j += 2 * RS_NT)
             *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(obj + j);
         if (t == 0) {
@@ -323,7 +330,8 @@ size_t resident_group_lds(int R, int C, int ld, int grid)
 {
     const int m = R - 1;
     const int rpw = (m + grid - 1) / grid;
-    return sizeof(double) * ((size_t)(rpw + 2) * ld + 2 * (size_t)((m + 1) & ~1) + (size_t)rpw + 2);
+    (void)ld;                                   // LDS rows are only as wide as the tableau (even), not the HBM pitch
+    return sizeof(double) * ((size_t)(rpw + 2) * ((C + 1) & ~1) + (size_t)((m + 1) & ~1) + (size_t)rpw + 2);
 }
 
 hipError_t resident_group_init()
@@ -335,6 +343,8 @@ hipError_t resident_group_init()
 hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s)
 {
     ResGroupParams p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
+    static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
+    p.mute = mute;
     hipLaunchKernelGGL(lpx_resident_group, dim3(grid, nodes), dim3(RS_NT), lds, s, p);
     return hipGetLastError();
 }

@@ -487,7 +487,8 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
 }
 
 int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
-                       int* statuses, lpx_stats* stats, int grid, int slots, size_t lds, lpx_pivot_cb cb, void* user)
+                       int* statuses, lpx_stats* stats, int grid, int slots, size_t lds, lpx_pivot_cb cb, void* user,
+                       DevState* resume = nullptr)
 {
     ResGroupBuf& g = g_resgroup;
     if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
@@ -517,7 +518,6 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = dual[i] ? 0 : 2;
         g.hs[i] = init;
         LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[i], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
-        LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
     }
     // launch length: long enough to hide the launch + reload (~30 us), short enough that a node finishing inside a
     // launch does not leave its slice idle for long
@@ -529,7 +529,11 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     long long launches = 0;
     while (!live.empty()) {
         const int n = (int)live.size() < slots ? (int)live.size() : slots;
-        for (int k = 0; k < n; ++k) g.h[k] = node[live[k]];
+        for (int k = 0; k < n; ++k) {
+            g.h[k] = node[live[k]];
+            lpx_tableau* t = ts[live[k]];          // basis as of the start of this launch (a launch that cannot finish writes nothing else back)
+            LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
+        }
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
         LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
         for (int k = 0; k < n; ++k)
@@ -540,12 +544,16 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         if (aborted) {
             for (int k = 0; k < n; ++k) resident_buffers_clear(ts[live[k]]);
             set_error("resident group loop: an exchange wait expired (workgroups not co-resident?)");
-            if (launches == 0) {
-                for (int i = 0; i < count; ++i)
-                    LPX_HIP_TRY(hipMemcpy(ts[i]->basis, ts[i]->xbasis, sizeof(int32_t) * (size_t)(ts[i]->R - 1), hipMemcpyDeviceToDevice));
-                return LPX_RESIDENT_RETRY;                   // nothing was written back: the caller streams the batch
+            // Nothing of this launch was written back: the nodes in it are as the previous launch left them (basis
+            // restored here); the caller finishes every unfinished node on the batched streaming kernels.
+            for (int k = 0; k < n; ++k) {
+                lpx_tableau* t = ts[live[k]];
+                LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
+                g.hs[live[k]].pad[1] = 0;
             }
-            return LPX_EDEVICE;
+            for (int i = 0; i < count; ++i) statuses[i] = g.hs[i].status;      // LPX_RUNNING marks the unfinished ones
+            if (resume) std::memcpy(resume, g.hs, sizeof(DevState) * count);
+            return LPX_RESIDENT_RETRY;
         }
         ++launches;
         if (launches > 4LL * count * ((long long)popts->max_iter + dopts->max_iter + dopts->fdf_guard) / chunk + 64) {
@@ -620,7 +628,7 @@ struct GroupRun {
     int max_nblk = 1, max_blocks = 1; bool done = true;
 };
 
-int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
+int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevState* inits = nullptr)
 {
     GroupBuf& g = *r.g;
     const int K = (int)r.idx.size();
@@ -639,6 +647,11 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
         if (ub > r.max_blocks) r.max_blocks = ub;
         DevState init; std::memset(&init, 0, sizeof(init));
         init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = r.dual ? 0 : 2;
+        if (inits) {                                // continue where another path stopped (pivot count, phase, counters)
+            const DevState& s0 = inits[r.idx[k]];
+            init.iter = s0.iter; init.phase = r.dual ? s0.phase : 2;
+            init.fdf_count = s0.fdf_count; init.dual_iter = s0.dual_iter; init.primal_count = s0.primal_count;
+        }
         g.hs[k] = init;
         LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[k], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
     }
@@ -691,13 +704,13 @@ int group_complete(GroupRun& r)
 }  // namespace
 
 static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
-                             const lpx_run_opts* dopts, int* statuses, lpx_stats* stats)
+                             const lpx_run_opts* dopts, int* statuses, lpx_stats* stats, const DevState* inits = nullptr)
 {
     GroupRun runs[2];
     for (int w = 0; w < 2; ++w) { runs[w].g = &g_groups[w]; runs[w].dual = w; }
     for (int i = 0; i < count; ++i) runs[dual[i] ? 1 : 0].idx.push_back(i);
     const double t0 = now_ms();
-    for (int w = 0; w < 2; ++w) if (!runs[w].idx.empty()) { int rc = group_begin(runs[w], ts, w ? dopts : popts); if (rc) return rc; }
+    for (int w = 0; w < 2; ++w) if (!runs[w].idx.empty()) { int rc = group_begin(runs[w], ts, w ? dopts : popts, inits); if (rc) return rc; }
     for (;;) {
         bool any = false;
         for (int w = 0; w < 2; ++w) if (!runs[w].done) { int rc = group_submit(runs[w], ts, w ? dopts : popts); if (rc) return rc; any = true; }
@@ -756,11 +769,20 @@ int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
         int grid = 0, slots = 0; size_t lds = 0; int isdual = 1, status = 0;
         if (!t->resident_off && resident_group_plan(&t, 1, &grid, &slots, &lds)) {
-            const int rc = run_resident_group(&t, &isdual, 1, o, o, &status, st, grid, slots, lds, cb, user);
+            DevState resume;
+            const int rc = run_resident_group(&t, &isdual, 1, o, o, &status, st, grid, slots, lds, cb, user, &resume);
             if (rc == 0) return status;
             if (rc != LPX_RESIDENT_RETRY) return rc;
             t->resident_off = true;
             if (o->resident > 0) return LPX_EDEVICE;
+            // hand over to the streaming kernels at the pivot the resident loop had reached
+            SelParams p = base_params(t, o, MODE_DUAL);
+            LoopCtx c; DevState init;
+            make_ctx(t, p, c, init);
+            init.iter = resume.iter; init.phase = resume.phase;
+            init.fdf_count = resume.fdf_count; init.dual_iter = resume.dual_iter; init.primal_count = resume.primal_count;
+            c.start_iter = resume.iter;
+            return run_device_loop(c, init, o, (long long)o->fdf_guard + 2LL * o->max_iter + 8, cb, user, st);
         } else
         if (o->resident > 0) { set_error("lpx_dual_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
@@ -989,18 +1011,46 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
     lpx_run_opts pd, dd;
     if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
     if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
-    // Nodes small enough to live on chip a few at a time (lpx_resident_group.hip).  Opt-in (LPX_RESIDENT_GROUP=1): on the
-    // degenerate 0/1 programs of config 4 the exact hysteresis scan dominates every pivot and three resident nodes are
-    // no faster than 32 streaming ones (251 vs 267 LP/s), so the batched streaming run stays the default.
-    static const bool resgroup_env = [] { const char* e = std::getenv("LPX_RESIDENT_GROUP"); return e && e[0] == '1'; }();
+    // Nodes small enough to live on chip a few at a time (lpx_resident_group.hip): four 8 MB nodes of config 4 run side by
+    // side, 25 % faster than 32 of them streaming through HBM.  LPX_RESIDENT_GROUP=0 keeps the batched streaming run.
+    static const bool resgroup_env = [] { const char* e = std::getenv("LPX_RESIDENT_GROUP"); return !(e && e[0] == '0'); }();
     if (resgroup_env && count >= 1 && !popts->profile && !dopts->profile && popts->resident >= 0 && dopts->resident >= 0) {
         bool ok = true;
-        for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2 || ts[i]->resident_off) ok = false;
+        for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2 || ts[i]->resident_off || (!dual[i] && !ts[i]->us)) ok = false;
         int grid = 0, slots = 0; size_t lds = 0;
         if (ok && resident_group_plan(ts, count, &grid, &slots, &lds)) {
-            const int rc = run_resident_group(ts, dual, count, popts, dopts, statuses, stats, grid, slots, lds, nullptr, nullptr);
+            std::vector<DevState> resume(count);
+            const int rc = run_resident_group(ts, dual, count, popts, dopts, statuses, stats, grid, slots, lds, nullptr, nullptr, resume.data());
             if (rc != LPX_RESIDENT_RETRY) return rc;
-            for (int i = 0; i < count; ++i) ts[i]->resident_off = true;
+            // some workgroup could not take part (GPU shared with another process?): finish the unfinished nodes on the
+            // batched streaming kernels, from the pivot each of them had reached
+            std::vector<lpx_tableau*> sub; std::vector<int> sdual, sidx; std::vector<DevState> sinit;
+            for (int i = 0; i < count; ++i) {
+                ts[i]->resident_off = true;
+                if (statuses[i] == LPX_RUNNING) { sub.push_back(ts[i]); sdual.push_back(dual[i]); sidx.push_back(i); sinit.push_back(resume[i]); }
+                else if (stats) { std::memset(&stats[i], 0, sizeof(lpx_stats)); stats[i].pivots = resume[i].iter; stats[i].fdf_pivots = resume[i].fdf_count; stats[i].cleanup_pivots = dual[i] ? resume[i].primal_count : 0; *ts[i]->hst = resume[i]; }
+            }
+            if (!sub.empty()) {
+                std::vector<int> sst(sub.size()); std::vector<lpx_stats> sss(sub.size());
+                int rc2;
+                if (sub.size() >= 2) rc2 = multi_run_batched(sub.data(), sdual.data(), (int)sub.size(), popts, dopts, sst.data(), sss.data(), sinit.data());
+                else {
+                    // a single straggler: its own streaming loop, continuing at its pivot count
+                    lpx_tableau* t = sub[0];
+                    const lpx_run_opts* o = sdual[0] ? dopts : popts;
+                    SelParams p = base_params(t, o, sdual[0] ? MODE_DUAL : MODE_PRIMAL);
+                    LoopCtx c; DevState init;
+                    make_ctx(t, p, c, init);
+                    init.iter = sinit[0].iter; init.phase = sdual[0] ? sinit[0].phase : 2;
+                    init.fdf_count = sinit[0].fdf_count; init.dual_iter = sinit[0].dual_iter; init.primal_count = sinit[0].primal_count;
+                    const long long budget = sdual[0] ? (long long)o->fdf_guard + 2LL * o->max_iter + 8 : (long long)o->max_iter + 2;
+                    rc2 = run_device_loop(c, init, o, budget, nullptr, nullptr, &sss[0]);
+                    if (rc2 >= 0) { sst[0] = rc2; rc2 = 0; }
+                }
+                if (rc2) return rc2;
+                for (size_t k = 0; k < sub.size(); ++k) { statuses[sidx[k]] = sst[k]; if (stats) stats[sidx[k]] = sss[k]; }
+            }
+            return 0;
         }
     }
     static const bool batched_env = [] { const char* e = std::getenv("LPX_BATCHED"); return !(e && e[0] == '0'); }();

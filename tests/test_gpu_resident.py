@@ -180,7 +180,7 @@ def test_resident_falls_back_to_streaming_when_a_workgroup_is_missing(oracle):
 
 
 def test_resident_group_multi_run_matches_streaming_batch(oracle):
-    """LPX_RESIDENT_GROUP=1: lpx_multi_run keeps a few node LPs resident at once (lpx_resident_group, blockIdx.y = node)
+    """lpx_multi_run keeps a few node LPs resident at once (lpx_resident_group, blockIdx.y = node)
     and refills the slices between launches.  Mixed primal / dual nodes of different shapes must end bit-identical to
     the oracle -- and so to the default batched streaming run."""
     import subprocess, sys, os, textwrap
@@ -216,7 +216,7 @@ def test_resident_group_multi_run_matches_streaming_batch(oracle):
         assert max(ss["launches"] for ss in stats) < 50      # launches of the group kernel, not 2 per pivot
         print("OK")
     ''')
-    env = dict(os.environ, LPX_RESIDENT_GROUP="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
@@ -243,3 +243,48 @@ def test_dual_resident_and_streaming_paths_agree_with_the_oracle(gpu, oracle, cl
                 assert dt.trace().tolist() == tr_ref.tolist() and bg.tolist() == br.tolist()
                 assert np.array_equal(_bits(Tg), _bits(Tr))
                 assert st["fdf_pivots"] == nf and (st["launches"] <= 2) == (res == 1)
+
+
+@pytest.mark.parametrize("mute", ["1", "2"])
+def test_group_kernel_hands_over_to_the_streaming_kernels(oracle, mute):
+    """LPX_RESIDENT_TEST_MUTE makes one workgroup of the group kernel play dead (1: from the first launch, 2: from the
+    second launch on).  lpx_multi_run must finish every unfinished node on the batched streaming kernels from the pivot
+    it had reached, lpx_dual_run likewise -- same bits as the oracle, callbacks complete and in order."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        from oracle import oracle as O
+        tabs, refs = [], []
+        for k in range(7):                                   # more nodes than slices, each longer than one 96-pivot launch
+            c, A, b = synth.dense_lp(220 + 9 * k, 330 + 7 * k, seed=500 + k)
+            A2, b2 = A.copy(), b.copy()
+            A2[: 2 + k % 3] *= -1.0; b2[: 2 + k % 3] *= -0.05       # a few >= rows (feasible): negative right-hand sides
+            T, basis = synth.primal_tableau_from(c, A2, b2)
+            Tr, br = T.copy(), basis.copy()
+            st, tr, nf = O.dual_tableau(Tr, br, fdf_guard=10000, cleanup=1)
+            assert len(tr) > 110
+            tabs.append((T, basis)); refs.append((st, Tr, br, tr))
+        hs = [L.DeviceTableau.from_host(T, basis) for T, basis in tabs]
+        o = L.default_opts(True, fdf_guard=10000, cleanup=1)
+        statuses, stats = L.multi_run(hs, [1] * len(hs), dual_opts=o)
+        for h, (st, Tr, br, tr), s, ss in zip(hs, refs, statuses, stats):
+            Tg, bg = h.download()
+            assert s == st and ss["pivots"] == len(tr), (s, st, ss["pivots"], len(tr))
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+            assert h.trace().tolist() == tr.tolist()
+        # single LP with callbacks, 32 pivots per launch
+        T, basis = tabs[3]; st, Tr, br, tr = refs[3]
+        ev = []
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, s1 = dt.dual_run(L.default_opts(True, fdf_guard=10000, cleanup=1, batch=32), cb=lambda it, r, q: ev.append((it, r, q)))
+            Tg, bg = dt.download()
+            assert status == st and s1["pivots"] == len(tr)
+            assert [e[0] for e in ev] == list(range(1, len(tr) + 1)) and [(e[1], e[2]) for e in ev] == [tuple(x) for x in tr.tolist()]
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+        print("OK")
+    ''')
+    env = dict(os.environ, LPX_RESIDENT_TEST_MUTE=mute, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
