@@ -296,7 +296,11 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
     bool any_warm = false; for (NodeLP* lp : group) if (lp->warm) any_warm = true;
-    if (any_warm) { dopt.fdf_guard = 0; dopt.cleanup = 1; }       // dual feasible start: only the dual loop (and its clean-up) runs
+    if (any_warm) {                                               // dual feasible start: only the dual loop (and its clean-up) runs
+        dopt.fdf_guard = 0; dopt.cleanup = 1;
+        // a warm-started node needs a few dozen pivots: 64 of them streaming together beat four resident at a time
+        dopt.resident = -1; po.resident = -1;
+    }
     if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
         for (NodeLP* lp : group) {
             if (c.count_work) c.out->LpSolves++;
