@@ -522,7 +522,8 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     // launch length: long enough to hide the launch + reload (~30 us), short enough that a node finishing inside a
     // launch does not leave its slice idle for long
     const lpx_run_opts* o0 = dual[0] ? dopts : popts;
-    const int chunk = cb ? (o0->batch > 0 ? o0->batch : 256) : (count > slots ? 96 : 1024);
+    static const int chunk_env = [] { const char* e = std::getenv("LPX_GROUP_CHUNK"); return e ? std::atoi(e) : 0; }();   // diagnostic
+    const int chunk = cb ? (o0->batch > 0 ? o0->batch : 256) : (count > slots ? (chunk_env > 0 ? chunk_env : 96) : 1024);
     std::vector<int> live(count);
     for (int i = 0; i < count; ++i) live[i] = i;
     std::vector<int> fired(count, 0);
