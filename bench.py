@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--headline-pivots", type=int, default=200)
     ap.add_argument("--cpu-sample-pivots", type=int, default=10000)
     ap.add_argument("--bnb-nodes", type=int, default=400, help="node budget per rank (config 4 leg)")
-    ap.add_argument("--bnb-concurrent", type=int, default=32)
+    ap.add_argument("--bnb-concurrent", type=int, default=64)
     ap.add_argument("--bnb-warm-nodes", type=int, default=4000, help="node budget per rank (warm-start leg)")
     ap.add_argument("--bnb-warm-concurrent", type=int, default=64)
     ap.add_argument("--knap-nodes", type=int, default=200000, help="pop budget per rank (config 5 leg)")

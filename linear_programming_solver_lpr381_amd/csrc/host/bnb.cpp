@@ -37,10 +37,10 @@ struct Cut { int var; Rel rel; double bound; };
 
 // LPX_BNB_TIMING=1: print where the host spends its time (diagnostic)
 struct PhaseTimer {
-    double build = 0, run = 0, collect = 0, decide = 0; bool on = false;
+    double build = 0, run = 0, collect = 0, decide = 0, root = 0, total = 0; bool on = false;
     PhaseTimer() { const char* e = std::getenv("LPX_BNB_TIMING"); on = e && e[0] == '1'; }
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] build %.1f ms, run %.1f ms, collect %.1f ms, decide %.1f ms\n", build, run, collect, decide); }
+    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] root %.1f ms, build %.1f ms, run %.1f ms, collect %.1f ms, decide %.1f ms, whole solves %.1f ms\n", root, build, run, collect, decide, total); }
 };
 static PhaseTimer g_pt;
 
@@ -599,12 +599,14 @@ SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot update
 {
     BestObjective = -INFINITY; BestSolution.clear(); HasBest = false;
     SimplexResult out;
+    struct Whole { double t0 = PhaseTimer::now(); ~Whole() { g_pt.total += PhaseTimer::now() - t0; } } whole;
     Ctx c; c.root = &problem; c.opt = opt; c.cb = updatePivot; c.out = &out;
     c.log("=== Branch & Bound Algorithm ===");
     const char* rootAlgo = has_ge_or_eq(problem) ? "Dual Simplex" : "Primal Simplex";     // :50
     c.log(std::string("Branch & Bound: Using ") + rootAlgo + " for the ROOT LP relaxation.");
 
     EngineOptions lopt = opt; lopt.dual_flags = opt.bnb_mode == 1 ? LPX_DUAL_REPAIRED : 0;
+    lopt.quiet = true;                  // the root LP's Report text is not part of the B&B result (:99-122)
     LPSolver solver(lopt);
     SimplexResult rootRes;
     out.LpSolves = 1;
@@ -617,7 +619,7 @@ SimplexResult BranchAndBound::Solve(const LPProblem& problem, UpdatePivot update
             if (lp.error) throw LpxException(LPX_EINVAL, "root relaxation failed");
             rootRes.HasSolution = lp.has_solution; rootRes.Solution = lp.x; rootRes.OptimalValue = lp.z;
         } else
-        rootRes = solver.Solve(problem, rootAlgo, nullptr);                               // :57
+        { const double t0 = PhaseTimer::now(); rootRes = solver.Solve(problem, rootAlgo, nullptr); g_pt.root += PhaseTimer::now() - t0; }   // :57
     } catch (const LpxException& ex) {
         if (ex.code == LPX_EDEVICE || ex.code == LPX_ENOMEM) throw;
         c.log(std::string("Root Problem: LP relaxation infeasible or error: ") + ex.what());

@@ -83,6 +83,8 @@ struct EngineOptions {
     std::function<void(double* vals, int count)> allreduce_max;
     int max_iter = 10000;
     int bnb_dive = 0;                // sharded searches: 1 = depth-first-K pool policy
+    bool quiet = false;              // internal solves whose Report nobody reads (B&B nodes): skip the canonical-form text,
+                                     // hundreds of thousands of formatted numbers for a config-4 model
     // test seams (see include/lpx.h); never set by product code
     std::function<int(double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
                       double* x, double* z, int64_t* pivots)> test_node_lp;

@@ -227,7 +227,7 @@ SimplexResult PrimalSimplex::Solve(const LPProblem& original, UpdatePivot update
             throw LpxException(LPX_E_NEG_RHS, "Constraint has a negative RHS value. The Primal Simplex method cannot handle this. Please try the Dual Simplex algorithm instead.");
     }
     LPProblem tableauModel = ExpandEqualitiesToInequalities(model);                     // :80
-    std::string report = AppendCanonicalForm(tableauModel);                             // :82
+    std::string report = opt.quiet ? std::string() : AppendCanonicalForm(tableauModel); // :82
     std::vector<double> T; int R, C; std::vector<int32_t> basis; std::vector<std::string> varNames;
     BuildTableauPrimal(tableauModel, T, R, C, basis, varNames);                         // :85
     if (updatePivot) updatePivot(AppendTableau("TABLEAU Iteration", T.data(), R, C, basis, varNames, 0), nullptr);   // :88-90
