@@ -25,6 +25,11 @@
 #include "lpx_resident.h"
 #include <cstdlib>
 
+#ifndef RS_SLEEP_A
+#define RS_SLEEP_A 15        // consumer's timed first look at the pivot row: A + B * ceil(C / 1024), x 64 cycles
+#define RS_SLEEP_B 5
+#endif
+
 namespace lpx {
 
 struct ResParams {
@@ -173,8 +178,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
             // on its way: 255 workgroups re-reading 48 KB each per failed poll would saturate the fabric.
             // The owner needs 0.5-1 us to divide and store the row: sleep through that, then try the
             // whole gather ONCE -- when the row is already visible this saves the canary's round trip.
-            __builtin_amdgcn_s_sleep(15);
-            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);   // measured best: 20 (C = 769) ... 35 (C = 3073) x 64 cycles
+            __builtin_amdgcn_s_sleep(RS_SLEEP_A);
+            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(RS_SLEEP_B);   // measured best: 20 (C = 769) ... 35 (C = 3073) x 64 cycles
             bool first = true;
             for (int base = t; base < C; base += RS_NT * RS_FETCH) {
                 int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
