@@ -358,6 +358,21 @@ def main():
                                     "algorithmic_bytes_per_launch": halg,
                                     "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}
         hd.close()
+        # the LP-level shape of the same m, n: tableau 4097 x 12289 = 403 MB
+        LR, LC = 4097, 12289
+        Tl = synth.raw_tableau(LR, LC)
+        ld_ = L.DeviceTableau.from_host(Tl)
+        rows, cols = synth.forced_pivot_list(LR, LC, 10 + 100)
+        ld_.forced_pivots(rows[:10], cols[:10], 0.1)
+        _, lst = ld_.forced_pivots(rows[10:], cols[10:], 0.1, profile=1, batch=100)
+        lk_ms = lst["update_ms_sum"] / max(lst["update_launches"], 1)
+        lalg = 16.0 * LR * LC
+        out["roofline_headline"]["lp_level_shape"] = {"shape": [LR, LC], "avg_kernel_us": 1e3 * lk_ms,
+                                                      "achieved": lalg / (lk_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                                      "frac": lalg / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      "launches": lst["update_launches"], "algorithmic_bytes_per_launch": lalg}
+        ld_.close()
+        del Tl
         progress("revised leg (config 3)")
         # ---- config 3: revised simplex m=4096 n=8192 -----------------------------------------------------
         c3, A3, b3 = synth.dense_lp(4096, 8192)
