@@ -4,30 +4,32 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-value (pivots/s)   A "step" is one complete device-resident solve of BASELINE.json's config 2 (dense
-                   random LP m=1024 n=2048, primal tableau simplex, seed 20251003) from the slack basis:
-                   the tableau is restored from a pristine HBM snapshot (D2D, inside the timed region)
-                   and the pivot loop runs to OPTIMAL -- on the path the library picks itself: this
-                   25 MB tableau fits the chip's LDS, so it is the resident kernel (csrc/lpx_resident.hip).
-                   value = pivots of all ranks / max wall.
-                   A single LP does not shard (DESIGN.md "Multi-GPU"): with N ranks each rank solves its
-                   own replica on its own GPU ("replicas only", weak scaling).
+value (pivots/s)   The HBM-streaming workload: the dense random LP m=4096 n=8192 (the size BASELINE.json's
+                   configs[2] names; north_star's "4096x8192 dense tableau") solved by the primal tableau
+                   simplex.  Its tableau is 4097 x 12289 f64 = 403 MB -- larger than the 256 MiB Infinity
+                   Cache, so every pivot is a real HBM stream (the raw 4096x8192 shape is EXACTLY 256 MiB and
+                   is reported beside it as `roofline_north_star`).  A "step" restores the tableau from a
+                   pristine HBM snapshot (D2D, inside the timed region) and runs the first `--pivots-per-step`
+                   pivots of the solve from the slack basis -- default 10000, the reference's own iteration cap
+                   (Models/PrimalSimplex.cs:54,95-96; the full solve needs 80477 pivots) -- on the streaming
+                   kernels lpx_select_mb + lpx_update_mb.  value = pivots of all ranks / max wall.
+                   A single LP does not shard (DESIGN.md "Multi-GPU"): with N ranks each rank solves its own
+                   replica on its own GPU ("replicas only", weak scaling).
 Extra objects on the same JSON line (rank 0 unless stated):
-  roofline           the dominant kernel of THIS workload, lpx_resident_primal: algorithmic bytes
-                     (16*R*C per pivot x pivots of the launch) / kernel duration from HIP events on the
-                     library's stream.  The bytes are LDS traffic; HBM sees the tableau once per launch.
-  roofline_streaming lpx_update_mb (rank-1 pivot update of the streaming path) on the same workload:
-                     16*R*C per launch / average kernel duration from HIP events bound to each dispatch
-                     (hipExtLaunchKernelGGL start/stop events), plus the streaming loop's pivots/s.
-  roofline_headline  the same kernel on the north-star shape, raw 4096x8192 f64 tableau (268 MB, a true
-                     HBM stream), 200 timed pivots after 20 warm-ups; plus whole-loop pivots/s there.
-  cpu_baseline       CPU oracle (C port of the reference's scalar loops, 1 core) on the same LP.
-  revised            config 3: revised simplex m=4096 n=8192, iterations/s over a bounded run.
-  bnb                config 4: 0/1 IP n=512 m=256 (+512 bound rows), repaired mode, node queue SHARDED
-                     over all ranks (level-synchronous, one all-reduce(max) per level over RCCL);
-                     nodes/s = LP relaxations solved by all ranks / max wall.  All ranks take part.
-  knapsack           config 5: 100k-item 0/1 knapsack, best-first B&B with batched GPU bounds, sharded
-                     subtrees over all ranks; nodes/s = popped nodes of all ranks / max wall.
+  roofline             lpx_update_mb (rank-1 pivot update, Models/PrimalSimplex.cs:251-256) in THAT solve:
+                       16*R*C algorithmic bytes per launch / mean launch duration from HIP events bound to each
+                       dispatch on the library's stream (hipExtLaunchKernelGGL start/stop events), measured live.
+                       `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes over the same
+                       workload (profiles/, see `traffic_source`); PMC needs the profiler around the process.
+  roofline_north_star  the same kernel on the raw 4096x8192 tableau (forced pivots), 268 MB = the MALL size.
+  config2              BASELINE configs[1] (m=1024 n=2048): the LDS-resident persistent kernel (latency bound,
+                       no HBM roofline) and the streaming kernels on the same LP.
+  cpu_baseline         CPU oracle (C port of the reference's scalar loops), 1 core, on a bounded sample of the
+                       SAME 4097x12289 LP; plus an all-cores OpenMP courtesy figure and samples of the other legs.
+  revised              config 3: revised simplex m=4096 n=8192, iterations/s over a bounded run.
+  bnb / bnb_warm       config 4: 0/1 IP n=512 m=256 (+512 bound rows), repaired mode, node queue SHARDED over all
+                       ranks (one all-reduce(max) per level); nodes/s = LP relaxations of all ranks / max wall.
+  knapsack             config 5: 100k-item 0/1 knapsack, best-first B&B with batched GPU bounds, sharded subtrees.
 """
 import argparse
 import json
@@ -41,61 +43,44 @@ sys.path.insert(0, ROOT)
 
 METRIC = "simplex pivots/sec on dense m×n tableau; B&B nodes/sec at 1/2/4/8 GPUs"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PROFILE_ROUND = "r02"
 
 
-def rocprof_kernel_us(R, C, kernel="lpx::lpx_update_mb", profile="r01_g_kernel_by_shape.json"):
-    """Mean duration of the update kernel at this shape from the committed rocprofv3 --kernel-trace of this
-    same script (profiles/r01_g_kernel_by_shape.json, tools/trace_by_shape.py) -- the cross-check of the
-    HIP-event figure measured live below (events bracket the dispatch and read ~1.5 us longer on the 8 us
-    kernel, ~1 % on the 80 us one)."""
-    path = os.path.join(ROOT, "profiles", profile)
-    if not os.path.exists(path):
-        return None
+def update_kernel(R, C):
+    """(kernel name, grid size in threads) of the rank-1 update for an R x C tableau -- the key of the committed profile
+    summaries.  Mirrors launch_update_mb (csrc/lpx_kernels.hip): tableaux above 320 MiB take the streaming variant
+    (one wave per workgroup, 3 rows per wave, non-temporal loads and stores), smaller ones the 8-row / 256-lane one."""
     ld = (C + 15) // 16 * 16
+    if 8 * ld * R > (320 << 20):
+        return "lpx::lpx_update_mb_s", ((ld + 127) // 128) * ((R + 2) // 3) * 64
     units = ((ld + 127) // 128) * ((R + 7) // 8)
-    grid = ((units + 3) // 4) * 256
-    d = json.load(open(path))
-    e = d.get(f"{kernel}@grid{grid}x1")
+    return "lpx::lpx_update_mb", ((units + 3) // 4) * 256
+
+
+def committed_profile(name):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}")
+    return (json.load(open(path)), os.path.relpath(path, ROOT)) if os.path.exists(path) else (None, None)
+
+
+def rocprof_kernel_us(R, C):
+    """Mean duration of the update kernel at this shape in the committed rocprofv3 --kernel-trace of this script
+    (tools/trace_by_shape.py) -- a cross-check of the live HIP-event figure, NOT a measurement of this run."""
+    d, _ = committed_profile("kernel_by_shape.json")
+    kernel, grid = update_kernel(R, C)
+    e = d.get(f"{kernel}@grid{grid}x1") if d else None
     return e["mean_ns_live"] / 1e3 if e else None
 
 
 def pmc_traffic(R, C):
-    """HBM bytes per launch of the update kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE in separate runs of tools/k4_headline.py, FETCH doubled per the gfx950
-    correction of MI355X_MICROARCH.md; tools/pmc_summarise.py).  PMC collection needs rocprofv3 around
-    the process, so it cannot happen inside this script; None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    ld = (C + 15) // 16 * 16
-    units = ((ld + 127) // 128) * ((R + 7) // 8)
-    grid = ((units + 3) // 4) * 256
-    d = json.load(open(path))
-    for k, v in d.items():
-        if k.endswith(f"@grid{grid}"):
-            return v["hbm_bytes_per_launch"]
-    return None
-
-
-def rocprof_resident_us():
-    """Mean duration of the full-solve launches of lpx_resident_primal in the committed rocprofv3 --kernel-trace
-    of this script (profiles/r01_g_kernel_by_shape.json, tools/trace_by_shape.py); None until it exists."""
-    path = os.path.join(ROOT, "profiles", "r01_g_kernel_by_shape.json")
-    if not os.path.exists(path):
-        return None
-    for k, e in json.load(open(path)).items():
-        if k.startswith("lpx::lpx_resident_primal@"):
-            return e["mean_ns_live"] / 1e3
-    return None
-
-
-def resident_traffic(R, C):
-    """HBM bytes per launch of lpx_resident_primal from the committed PMC passes (profiles/r01_pmc_resident.json,
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes); None until collected."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_resident.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path)).get("hbm_bytes_per_launch")
+    """HBM bytes per launch of lpx_update_mb from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    in separate runs, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md; tools/pmc_summarise.py)."""
+    d, src = committed_profile("pmc_traffic.json")
+    if d:
+        kernel, grid = update_kernel(R, C)
+        v = d.get(f"{kernel}@grid{grid}")
+        if v:
+            return v["hbm_bytes_per_launch"], src
+    return None, None
 
 
 def progress(msg):
@@ -109,13 +94,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--m", type=int, default=1024)
-    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--pivots-per-step", type=int, default=10000,
+                    help="pivots of the solve per step (default: the reference's iteration cap)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline value")
+    ap.add_argument("--roofline-pivots", type=int, default=400)
     ap.add_argument("--headline-pivots", type=int, default=200)
-    ap.add_argument("--cpu-sample-pivots", type=int, default=10000)
+    ap.add_argument("--cpu-sample-pivots", type=int, default=240)
     ap.add_argument("--bnb-nodes", type=int, default=400, help="node budget per rank (config 4 leg)")
     ap.add_argument("--bnb-concurrent", type=int, default=64)
     ap.add_argument("--bnb-warm-nodes", type=int, default=4000, help="node budget per rank (warm-start leg)")
@@ -139,6 +127,7 @@ def main():
     # uses device r % device_count) and the collectives run over gloo on CPU tensors.  The driver's runs
     # use the default: one rank per GPU, RCCL ("nccl").
     backend = os.environ.get("LPX_BENCH_BACKEND", "nccl")
+    backend_name = "RCCL over xGMI" if backend == "nccl" else f"{backend} (rehearsal backend, CPU tensors)"
     dev = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev)
     L._lib.check(L._lib.lib().lpx_init(dev))
@@ -155,7 +144,7 @@ def main():
         torch.cuda.synchronize()
 
     def allreduce_max(vals):
-        """X1: the incumbent exchange -- one RCCL all-reduce(max) over xGMI per level / round."""
+        """X1: the incumbent exchange -- one all-reduce(max) per level / round."""
         if world == 1:
             return vals
         t = torch.from_numpy(np.ascontiguousarray(vals)).to(coll_dev)
@@ -171,22 +160,23 @@ def main():
         dist.all_reduce(b, op=dist.ReduceOp.MAX)
         return float(a.item()), float(b.item())
 
-    # ---- headline workload: config 2 ------------------------------------------------------------
+    # ---- headline workload: primal tableau simplex on the m=4096 n=8192 LP (tableau 403 MB) -------
     m, n = args.m, args.n
     c, A, b = synth.dense_lp(m, n, seed=synth.SEED + rank)   # one replica per rank, own seed
     T, basis = synth.primal_tableau_from(c, A, b)
+    del A
     R, C = T.shape
     dt = L.DeviceTableau.from_host(T, basis)
     dt.snapshot()
-    opts = L.default_opts(False, batch=args.batch, use_graph=0 if args.no_graph else 1)
+    opts = L.default_opts(False, batch=args.batch, use_graph=0 if args.no_graph else 1, max_iter=args.pivots_per_step)
 
     def step():
         dt.restore()
         status, st = dt.primal_run(opts)
-        assert status == 0, f"solve ended with status {status}"
+        assert status in (0, 3), f"solve ended with status {status}"     # OPTIMAL, or the iteration cap of the step
         return st
 
-    progress("config 2 solves")
+    progress(f"headline solves ({R}x{C}, {args.pivots_per_step} pivots per step)")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -208,23 +198,25 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * wall / args.steps,
+        "ms_per_step": 1e3 * wall / max(args.steps, 1),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"dense random LP m={m} n={n}, primal tableau simplex (config 2), "
-                        f"tableau {R}x{C} f64, solved to OPTIMAL from the slack basis",
+            "workload": f"dense random LP m={m} n={n}, primal tableau simplex, tableau {R}x{C} f64 "
+                        f"({R * C * 8 / 1e6:.0f} MB > 256 MiB Infinity Cache), first {args.pivots_per_step} pivots "
+                        "from the slack basis per step (the reference's iteration cap, Models/PrimalSimplex.cs:54)",
             "parallelism": "replicas only (one LP per GPU)" if world > 1 else "1 GPU",
             "pivots_per_step": pivots / max(args.steps, 1),
             "batch": args.batch,
             "hipgraph": not args.no_graph,
             "device_loop_ms_per_step": loop_ms / max(args.steps, 1),
-            "path": "resident (tableau in LDS, lpx_resident_primal: 1 launch per solve)" if st["launches"] <= 2
-                    else "streaming (lpx_select_mb + lpx_update_mb per pivot)",
+            "path": "streaming (lpx_select_mb + lpx_update_mb per pivot)" if st["launches"] > 2
+                    else "resident (tableau in LDS, 1 launch per solve)",
             "launches_per_step": st["launches"],
+            "restore_inside_timed_region": True,
         },
     }
 
@@ -247,7 +239,9 @@ def main():
                                   f"{args.bnb_nodes}, {args.bnb_concurrent} node LPs in flight per GPU",
                       "nodes_per_s": lp_total / tb_max, "lp_relaxations": lp_total, "pivots": piv_total,
                       "wall_s": tb_max, "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
-                      "collective": "1 all-reduce(max) of {incumbent, have_work} per level (RCCL)" if world > 1 else "none (1 rank)"}
+                      "collective": f"1 all-reduce(max) of {{incumbent, have_work}} per level ({backend_name})"
+                                    if world > 1 else "none (1 rank)",
+                      "multi_gpu_status": "unmeasured on hardware (no 8-GPU run yet)"}
         # ---- config 4 again with warm-started children (NOT the reference's re-solve) ------
         bnbw = L.BranchAndBound(bnb_mode=1, bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent,
                                 max_nodes=args.bnb_warm_nodes, rank=rank, world=world, allreduce_max=allreduce_max)
@@ -297,47 +291,25 @@ def main():
         copy_gbs = 10 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
         torch.cuda.empty_cache()
-        # ---- roofline of the dominant kernel of THIS workload -------------------------------------------
-        # Config 2's tableau (25 MB) fits the chip's LDS, so the solve above ran as ONE persistent kernel
-        # (lpx_resident_primal) that loads the tableau once, pivots in LDS and stores it once.  `achieved` keeps
-        # the contract's definition -- algorithmic bytes (16*R*C per pivot x the pivots of the launch) over the
-        # kernel's duration from HIP events on the library stream -- but those bytes are LDS traffic here, which
-        # is the point: HBM sees 16*R*C per LAUNCH (`hbm_bytes_per_launch_by_construction`).
+        # ---- roofline of the dominant kernel of THIS workload: lpx_update_mb in the real solve ------------
+        # profile = 1: eager launches, every update dispatch bracketed by its own HIP start/stop events on the
+        # library's stream (hipExtLaunchKernelGGL); the same pivots as the timed solve (same LP, same start).
         alg = 16.0 * R * C
         dt.restore()
-        status, rst = dt.primal_run(L.default_opts(False, resident=1, profile=1))
-        rk_ms = rst["update_ms_sum"] / max(rst["update_launches"], 1)
-        rach = alg * rst["pivots"] / (rk_ms * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "lpx_resident_primal", "bound": "hbm", "achieved": rach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": rach / HBM_PEAK_GBS, "traffic": resident_traffic(R, C),
-                           "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": rach / copy_gbs,
-                           "avg_kernel_us": 1e3 * rk_ms, "rocprof_avg_kernel_us": rocprof_resident_us(),
-                           "launches": rst["update_launches"], "pivots_per_launch": rst["pivots"],
-                           "us_per_pivot": 1e3 * rk_ms / max(rst["pivots"], 1),
-                           "algorithmic_bytes_per_launch": alg * rst["pivots"],
-                           "hbm_bytes_per_launch_by_construction": alg,
-                           "note": "tableau resident in LDS for the whole solve; per pivot only m ratios and the pivot "
-                                   "row cross CUs (tagged granules, ~64 KB), so the kernel is bound by two exchange "
-                                   "latencies per pivot, not by HBM; see roofline_streaming / roofline_headline for the "
-                                   "HBM-streaming kernel"}
-        # ---- the streaming kernels on the same workload (what runs when a tableau does not fit on chip) -----
-        popts = L.default_opts(False, batch=args.batch, profile=1, resident=-1)
-        dt.restore()
-        status, pst = dt.primal_run(popts)
+        status, pst = dt.primal_run(L.default_opts(False, batch=args.batch, profile=1, max_iter=args.roofline_pivots))
         k_ms = pst["update_ms_sum"] / max(pst["update_launches"], 1)
         ach = alg / (k_ms * 1e-3) / 1e9
-        dt.restore()
-        status, sst = dt.primal_run(L.default_opts(False, batch=args.batch, resident=-1))
-        out["roofline_streaming"] = {"kernel": "lpx_update_mb", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(R, C),
-                           "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": ach / copy_gbs,
-                           "avg_kernel_us": 1e3 * k_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(R, C),
+        traffic, traffic_src = pmc_traffic(R, C)
+        out["roofline"] = {"kernel": update_kernel(R, C)[0].split("::")[1], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src, "shape": [R, C],
+                           "algorithmic_bytes_per_launch": alg, "avg_kernel_us": 1e3 * k_ms,
                            "launches": pst["update_launches"],
-                           "algorithmic_bytes_per_launch": alg,
-                           "pivots_per_s_whole_loop": sst["pivots"] / (sst["loop_ms"] * 1e-3),
-                           "note": "25 MB tableau: resident in the 256 MiB Infinity Cache, not an HBM stream; "
-                                   "see roofline_headline for the HBM-streaming shape"}
-        # ---- headline shape: raw 4096x8192 tableau, forced pivots -------------------------------------
+                           "timing": "HIP start/stop events bound to each dispatch on the library stream, this run",
+                           "rocprof_avg_kernel_us_committed": rocprof_kernel_us(R, C),
+                           "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": ach / copy_gbs,
+                           "whole_loop_us_per_pivot": 1e3 * loop_ms / max(pivots, 1)}
+        # ---- north-star shape: raw 4096x8192 tableau (exactly 256 MiB = the Infinity Cache), forced pivots ----
         HR, HC = 4096, 8192
         Th = synth.raw_tableau(HR, HC)
         hd = L.DeviceTableau.from_host(Th)
@@ -349,30 +321,43 @@ def main():
         hach = halg / (hk_ms * 1e-3) / 1e9
         hd.upload(Th)
         _, hst2 = hd.forced_pivots(rows[20:], cols[20:], 0.1, batch=100)
-        out["roofline_headline"] = {"kernel": "lpx_update_mb", "shape": [HR, HC], "bound": "hbm",
-                                    "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": hach / HBM_PEAK_GBS, "traffic": pmc_traffic(HR, HC),
-                                    "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": hach / copy_gbs,
-                                    "avg_kernel_us": 1e3 * hk_ms, "rocprof_avg_kernel_us": rocprof_kernel_us(HR, HC),
-                                    "launches": hst["update_launches"],
-                                    "algorithmic_bytes_per_launch": halg,
-                                    "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3)}
+        htraffic, htraffic_src = pmc_traffic(HR, HC)
+        out["roofline_north_star"] = {"kernel": update_kernel(HR, HC)[0].split("::")[1], "shape": [HR, HC], "bound": "hbm",
+                                      "achieved": hach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": hach / HBM_PEAK_GBS, "traffic": htraffic, "traffic_source": htraffic_src,
+                                      "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": hach / copy_gbs,
+                                      "avg_kernel_us": 1e3 * hk_ms, "rocprof_avg_kernel_us_committed": rocprof_kernel_us(HR, HC),
+                                      "launches": hst["update_launches"], "algorithmic_bytes_per_launch": halg,
+                                      "pivots_per_s_whole_loop": hst2["pivots"] / (hst2["loop_ms"] * 1e-3),
+                                      "note": "4096*8192*8 B = 268435456 B is exactly the 256 MiB Infinity Cache: part of this "
+                                              "rate is cache residency; `roofline` above is the pure HBM stream"}
         hd.close()
-        # the LP-level shape of the same m, n: tableau 4097 x 12289 = 403 MB
-        LR, LC = 4097, 12289
-        Tl = synth.raw_tableau(LR, LC)
-        ld_ = L.DeviceTableau.from_host(Tl)
-        rows, cols = synth.forced_pivot_list(LR, LC, 10 + 100)
-        ld_.forced_pivots(rows[:10], cols[:10], 0.1)
-        _, lst = ld_.forced_pivots(rows[10:], cols[10:], 0.1, profile=1, batch=100)
-        lk_ms = lst["update_ms_sum"] / max(lst["update_launches"], 1)
-        lalg = 16.0 * LR * LC
-        out["roofline_headline"]["lp_level_shape"] = {"shape": [LR, LC], "avg_kernel_us": 1e3 * lk_ms,
-                                                      "achieved": lalg / (lk_ms * 1e-3) / 1e9, "unit": "GB/s",
-                                                      "frac": lalg / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                      "launches": lst["update_launches"], "algorithmic_bytes_per_launch": lalg}
-        ld_.close()
-        del Tl
+        del Th
+        # ---- config 2 (m=1024 n=2048, 25 MB): resident in LDS -- a latency-bound kernel, no HBM roofline -----
+        progress("config 2 leg")
+        c2, A2, b2 = synth.dense_lp(1024, 2048)
+        T2, basis2 = synth.primal_tableau_from(c2, A2, b2)
+        d2 = L.DeviceTableau.from_host(T2, basis2)
+        d2.snapshot()
+        d2.primal_run(L.default_opts(False))
+        d2.restore()
+        t2 = time.perf_counter()
+        status, rst = d2.primal_run(L.default_opts(False))
+        r_wall = time.perf_counter() - t2
+        d2.restore()
+        status, sst = d2.primal_run(L.default_opts(False, batch=args.batch, resident=-1))
+        d2.restore()
+        status, s2p = d2.primal_run(L.default_opts(False, batch=args.batch, resident=-1, profile=1, max_iter=600))
+        out["config2"] = {"workload": "dense random LP m=1024 n=2048 (config 2), tableau 1025x3073 f64 = 25 MB, solved to OPTIMAL",
+                          "resident": {"kernel": "lpx_resident_primal", "bound": "latency (two cross-CU exchanges per pivot; "
+                                                 "tableau in LDS, HBM sees it once per launch)",
+                                       "pivots": rst["pivots"], "launches": rst["launches"],
+                                       "pivots_per_s": rst["pivots"] / r_wall,
+                                       "us_per_pivot": 1e6 * r_wall / max(rst["pivots"], 1)},
+                          "streaming": {"kernels": "lpx_select_mb + lpx_update_mb", "bound": "Infinity Cache (25 MB tableau)",
+                                        "pivots_per_s": sst["pivots"] / (sst["loop_ms"] * 1e-3),
+                                        "update_avg_kernel_us": 1e3 * s2p["update_ms_sum"] / max(s2p["update_launches"], 1)}}
+        d2.close()
         progress("revised leg (config 3)")
         # ---- config 3: revised simplex m=4096 n=8192 -----------------------------------------------------
         c3, A3, b3 = synth.dense_lp(4096, 8192)
@@ -395,16 +380,18 @@ def main():
                           "refactor_note": "K7' = the reference's Invert (4096 Gauss-Jordan steps x 16*m*2m bytes), "
                                            "which the reference runs EVERY iteration; the engine runs it on demand"}
         rv.close()
+        del A3
         progress("CPU baselines")
-        # ---- CPU baseline: oracle (C port of the reference loops), 1 core -------------------------------
+        # ---- CPU baseline: oracle (C port of the reference loops), 1 core, bounded sample of the SAME LP ------
         if world == 1:
             from oracle import oracle as O
+            npv = args.cpu_sample_pivots
             Tc, bc = T.copy(), basis.copy()
             t2 = time.perf_counter()
-            st_c, tr_c = O.primal_tableau(Tc, bc, max_iter=args.cpu_sample_pivots)
+            st_c, tr_c = O.primal_tableau(Tc, bc, max_iter=npv)
             cpu_s = time.perf_counter() - t2
             out["cpu_baseline"] = {"value": len(tr_c) / cpu_s, "unit": "pivots/s", "cores": 1, "kind": "port",
-                                   "sample": f"all {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
+                                   "sample": f"first {len(tr_c)} pivots of the same {R}x{C} LP, oracle/primal.c "
                                              f"(gcc -O2 -ffp-contract=off, scalar), {cpu_s:.1f} s"}
             progress(f"CPU 1-core done ({cpu_s:.1f} s); all-cores baseline")
             try:
@@ -414,23 +401,28 @@ def main():
             out["cpu_baseline"]["cpu_model"] = model
             out["cpu_baseline"]["nproc"] = os.cpu_count()
             out["cpu_baseline"]["affinity_cpus"] = len(os.sched_getaffinity(0))
-            # courtesy strong baseline: the same loop with Pivot's rows spread over all host cores
-            # the box grants 16 CPUs per GPU whatever the affinity mask says; oversubscribed OpenMP
-            # teams spin in their barriers, so cap the team and make idle threads sleep
+            # courtesy strong baseline: the same loop with Pivot's rows spread over the host cores of this GPU's share
+            # (the box grants 16 CPUs per GPU whatever the affinity mask says; oversubscribed OpenMP teams spin)
             ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
             Tm, bm = T.copy(), basis.copy()
             t2 = time.perf_counter()
-            st_m, tr_m = O.primal_tableau(Tm, bm, max_iter=args.cpu_sample_pivots, threads=ncores)
+            st_m, tr_m = O.primal_tableau(Tm, bm, max_iter=npv, threads=ncores)
             mt_s = time.perf_counter() - t2
             assert np.array_equal(tr_m, tr_c) and np.array_equal(Tm, Tc)
+            del Tm, Tc
             out["cpu_baseline"]["all_cores"] = {"value": len(tr_m) / mt_s, "unit": "pivots/s", "cores": ncores,
                                                 "sample": f"same {len(tr_m)} pivots, oracle/primal_mt.c (OpenMP over "
                                                           f"the rows of Pivot, bit-identical), {mt_s:.1f} s"}
-            progress(f"all-cores done ({mt_s:.1f} s); revised CPU sample")
-            # reference-faithful revised path (Invert every iteration), bounded: 3 iterations at m=1024
-            c1, A1, b1 = synth.dense_lp(1024, 2048)
+            progress(f"all-cores done ({mt_s:.1f} s); config 2 / revised CPU samples")
+            Tc2, bc2 = T2.copy(), basis2.copy()
             t2 = time.perf_counter()
-            rr_c = O.revised_solve(O.Problem(O.MAX, c1, A1, np.zeros(1024, np.int32), b1), max_iter=3)
+            st_c2, tr_c2 = O.primal_tableau(Tc2, bc2, max_iter=1500)
+            c2_s = time.perf_counter() - t2
+            out["cpu_baseline"]["config2_pivots_per_s"] = len(tr_c2) / c2_s
+            out["cpu_baseline"]["config2_sample"] = f"first {len(tr_c2)} pivots of the 1025x3073 LP, 1 core, {c2_s:.1f} s"
+            # reference-faithful revised path (Invert every iteration), bounded: 3 iterations at m=1024
+            t2 = time.perf_counter()
+            rr_c = O.revised_solve(O.Problem(O.MAX, c2, A2, np.zeros(1024, np.int32), b2), max_iter=3)
             cr = time.perf_counter() - t2
             out["cpu_baseline"]["revised_iterations_per_s_m1024"] = len(rr_c.trace) / cr
             out["cpu_baseline"]["revised_sample"] = (f"first {len(rr_c.trace)} iterations at m=1024 n=2048, oracle/revised.c "

@@ -161,14 +161,16 @@ __device__ unsigned long long lpx_g_stamps[32];
 
 // FLY = true: sources in LDS -- each ratio is formed as soon as its two operands are read, so only the 16 ratios
 // stay live (32 VGPRs instead of 96; the resident kernels have 128 per lane and spill otherwise).
+// (seg0, best0, win0): continue a scan whose segments before row seg0 ended with the carried (best, position).
 template <class Src, bool FLY = false>
-__device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src)
+__device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src,
+                                                      int seg0 = 0, double best0 = __builtin_inf(), int win0 = -1)
 {
     const int lane = threadIdx.x & 63;
-    double best = __builtin_inf();
-    int win = -1;
+    double best = best0;
+    int win = win0;
     LPX_HS_BEGIN
-    for (int seg = 0; seg < L; seg += 64 * WH_PER) {
+    for (int seg = seg0; seg < L; seg += 64 * WH_PER) {
         double rt[WH_PER];
         if constexpr (FLY) {
 #pragma unroll
@@ -241,6 +243,59 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
             pos = found;
         }
         LPX_HS(5);
+    }
+    return win;
+}
+
+// The same scan with the segments of a long vector spread over the NW waves of a workgroup (multi-workgroup select at
+// m > 1024: one wave alone walks ceil(m / 1024) segments one after the other, 2.5-3.5 us each).  Per segment only three
+// things enter the chain -- its minimum, the first position of it, and whether that row is alone in the band
+// [min, min + tol] -- and none of them depends on what was carried in, so the segments are evaluated in parallel and the
+// chain is replayed over the <= 64 segment records by every lane.  A segment that would be entered through a tie / near-tie
+// hands over to the exact sequential scan from that segment on (carried best and position included): same winner, always.
+// All NW*64 lanes call this; one barrier.
+template <int NW, class Src>
+__device__ __forceinline__ int block_hysteresis_segments(int L, double tol, const Src& src)
+{
+    constexpr int SEG = 64 * WH_PER;
+    const int S = (L + SEG - 1) / SEG;
+    if (S <= 1 || S > 64) return wave_hysteresis_argmin(L, tol, src);
+    __shared__ double sg_v[64];
+    __shared__ int sg_i[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int sgi = wave; sgi < S; sgi += NW) {
+        const int seg = sgi * SEG;
+        double den[WH_PER], num[WH_PER], rt[WH_PER];
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) {
+            const int k = min(seg + u * 64 + lane, L - 1);
+            den[u] = src.den(k); num[u] = src.num(k);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) {
+            const int k = seg + u * 64 + lane;
+            rt[u] = (k < L) ? src.value(den[u], num[u]) : __builtin_inf();
+        }
+        MinIdx lm; lm.v = __builtin_inf(); lm.i = INT_MAX;
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) if (rt[u] < lm.v) { lm.v = rt[u]; lm.i = u * 64 + lane; }
+        lm = wave_min_idx(lm);
+        int inband = 0;
+#pragma unroll
+        for (int u = 0; u < WH_PER; ++u) inband += ((rt[u] - tol) <= lm.v) ? 1 : 0;
+        const bool clean = (__ballot(inband >= 2) == 0ull) && (__popcll(__ballot(inband == 1)) == 1);
+        if (lane == 0) { sg_v[sgi] = lm.v; sg_i[sgi] = clean ? seg + lm.i : -1; }
+    }
+    __syncthreads();
+    double best = __builtin_inf();
+    int win = -1;
+    for (int sgi = 0; sgi < S; ++sgi) {
+        const double v = sg_v[sgi];
+        if (!(v < best - tol)) continue;                 // nothing in this segment beats the carried best
+        const int i = sg_i[sgi];
+        if (i < 0) return wave_hysteresis_argmin(L, tol, src, sgi * SEG, best, win);    // ties: exact scan from here on
+        best = v; win = i;
     }
     return win;
 }

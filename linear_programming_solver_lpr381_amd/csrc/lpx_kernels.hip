@@ -312,7 +312,38 @@ __global__ __launch_bounds__(SEL_NT) void lpx_select_la(SelParams P)
 // ------------------------------------------------------------------------------------------------
 static constexpr int UPD_NT = 256;
 static constexpr int UPD_ROWS = 8;
+// Streaming variant for tableaux that cannot live in the 256 MiB Infinity Cache: one wave per workgroup, 3 rows per
+// wave, non-temporal loads AND stores (`nt`: the lines are not kept in L2 / MALL, where they would only evict each
+// other before the next pivot comes round).  Measured on 4097 x 12289 (403 MB), tools/kbench/store_variants.hip:
+// 8 rows x 256-lane workgroups, default policy 141.7 us (5.69 TB/s); 3 rows x 64 lanes with nt on both sides 126.9 us
+// (6.35 TB/s); nt on one side only, or nt with the 8-row tile, gains nothing.  Below ~1.2x the cache size the default
+// policy wins (4096 x 8192 = 256 MiB: 77.7 us vs 83-88 us), so the launcher switches on the tableau's size.
+static constexpr int UPDS_NT = 64;
+static constexpr int UPDS_ROWS = 3;
+static constexpr size_t UPD_STREAM_BYTES = (size_t)320 << 20;
 
+typedef double lpx_d2 __attribute__((ext_vector_type(2)));
+template <bool STREAM> __device__ __forceinline__ double2 upd_load(const double* p)
+{
+    if constexpr (STREAM) {
+        lpx_d2 v;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+        return make_double2(v.x, v.y);          // the caller waits (s_waitcnt vmcnt(0)) before the first use
+    } else {
+        return *reinterpret_cast<const double2*>(p);
+    }
+}
+template <bool STREAM> __device__ __forceinline__ void upd_store(double* p, double2 o)
+{
+    if constexpr (STREAM) {
+        lpx_d2 v; v.x = o.x; v.y = o.y;
+        asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<double2*>(p) = o;
+    }
+}
+
+template <int ROWS = UPD_ROWS, int NTH = UPD_NT, bool STREAM = false>
 __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
                                                 const int32_t* __restrict__ shape,
                                                 const double* __restrict__ prow,
@@ -331,37 +362,38 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
     const int qn = st->qn;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    const int unit = blockIdx.x * (NTH / 64) + wave;
     if (unit >= nunits) return;
     const int cw = unit % ncw;
     const int rb = unit / ncw;
     const int col = cw * 128 + lane * 2;
     if (col >= ld) return;                      // ld is a multiple of 16, so col+1 < ld too
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
-    const int row0 = rb * UPD_ROWS;
+    const int row0 = rb * ROWS;
     if (row0 >= R) return;
     double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);              // this lane owns column qn
     const bool wr = (rhsbuf != nullptr) && (((C - 1) & ~1) == col);   // this lane owns the RHS column
 
-    double2 v[UPD_ROWS];
-    double f[UPD_ROWS];
+    double2 v[ROWS];
+    double f[ROWS];
 #pragma unroll
-    for (int k = 0; k < UPD_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
-            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+            v[k] = upd_load<STREAM>(base + (size_t)k * ld);
             f[k] = fac[i];
         }
     }
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < UPD_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R && i != r) {
             double2 o;
             o.x = v[k].x - f[k] * p.x;          // mul, then sub: contraction is off
             o.y = v[k].y - f[k] * p.y;
-            *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
+            upd_store<STREAM>(base + (size_t)k * ld, o);
             if (wq) nxt[i] = (qn & 1) ? o.y : o.x;
             if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
         }
@@ -437,7 +469,9 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
         if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
         else if (q < 0) final_status = LPX_OPTIMAL;
         else {
-            r = wave_hysteresis_argmin(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps});   // every wave, no barrier
+            // every wave of every workgroup gets the same row: one wave each for m <= 1024 (no barrier), the segments of a
+            // longer column spread over the workgroup's waves
+            r = block_hysteresis_segments<MB_NT / 64>(m, P.tol_primal, RowRatio{colc, 1, P.rhsbuf, 1, P.eps});
             if (r < 0) final_status = LPX_UNBOUNDED;
             scanrow = m;
         }
@@ -488,6 +522,7 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
 
 // lpx_update for the multi-workgroup protocol: same streaming body; the next entering column comes from
 // the select workgroups' partials, and workgroup 0 commits the state record `us` for the next select.
+template <int ROWS = UPD_ROWS, int NTH = UPD_NT, bool STREAM = false>
 __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
                                                    const int32_t* __restrict__ shape,
                                                    const double* __restrict__ prow,
@@ -532,38 +567,39 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
     const double* __restrict__ fac = par ? fac1 : fac0;
     double* __restrict__ nxt = par ? fac0 : fac1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = blockIdx.x * (UPD_NT / 64) + wave;
+    const int unit = blockIdx.x * (NTH / 64) + wave;
     if (unit >= nunits) return;
     const int cw = unit % ncw;
     const int rb = unit / ncw;
     const int col = cw * 128 + lane * 2;
     if (col >= ld) return;
-    const int row0 = rb * UPD_ROWS;
+    const int row0 = rb * ROWS;
     if (row0 >= R) return;                                // capacity-sized grid: rows beyond the live shape
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
     double* base = T + (size_t)row0 * ld + col;
     const bool wq = (qn >= 0) && ((qn & ~1) == col);
     const bool wr = (((C - 1) & ~1) == col);
 
-    double2 v[UPD_ROWS];
-    double f[UPD_ROWS];
+    double2 v[ROWS];
+    double f[ROWS];
 #pragma unroll
-    for (int k = 0; k < UPD_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
-            v[k] = *reinterpret_cast<const double2*>(base + (size_t)k * ld);
+            v[k] = upd_load<STREAM>(base + (size_t)k * ld);
             f[k] = fac[i];
         }
     }
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < UPD_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
             double2 o;
             if (i != r) {
                 o.x = v[k].x - f[k] * p.x;      // mul, then sub: contraction is off
                 o.y = v[k].y - f[k] * p.y;
-                *reinterpret_cast<double2*>(base + (size_t)k * ld) = o;
+                upd_store<STREAM>(base + (size_t)k * ld, o);
             } else {
                 o = p;                          // row r already holds the normalised pivot row
             }
@@ -598,6 +634,20 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* T, int ld, int R
                                                         const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
 {
     lpx_update_mb_body(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+}
+// streaming variants (tableau larger than the Infinity Cache): see UPDS_ROWS above
+__global__ __launch_bounds__(UPDS_NT) void lpx_update_s(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                        const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                        const DevState* st, int ncw, int nunits)
+{
+    lpx_update_body<UPDS_ROWS, UPDS_NT, true>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+}
+__global__ __launch_bounds__(UPDS_NT) void lpx_update_mb_s(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                           const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                           const DevState* st, DevState* us, const double* part_v,
+                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
+{
+    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, true>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
 }
 // batched: every node of the group advances by one pivot per launch pair; grid.x covers the largest node
 __global__ __launch_bounds__(UPD_NT) void lpx_update_b(const SelParams* __restrict__ arr)
@@ -739,8 +789,24 @@ hipError_t launch_select_mb(const SelParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+static bool update_streams(int ld, int R) { return sizeof(double) * (size_t)ld * (size_t)R > UPD_STREAM_BYTES; }
+
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    if (update_streams(p.ld, p.R)) {
+        const int ncw = (p.ld + 127) / 128, nunits = ncw * ((p.R + UPDS_ROWS - 1) / UPDS_ROWS);
+        const int nblocks = (nunits + (UPDS_NT / 64) - 1) / (UPDS_NT / 64);
+        const int forced = p.mode == MODE_FORCED ? 1 : 0;
+        if (e0 && e1)
+            hipExtLaunchKernelGGL(lpx_update_mb_s, dim3(nblocks), dim3(UPDS_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
+                                  (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                                  (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+        else
+            hipLaunchKernelGGL(lpx_update_mb_s, dim3(nblocks), dim3(UPDS_NT), 0, s, p.T, p.ld, p.R, p.C, p.shape,
+                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                               (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+        return hipGetLastError();
+    }
     const int ncw = (p.ld + 127) / 128;
     const int nrb = (p.R + UPD_ROWS - 1) / UPD_ROWS;
     const int nunits = ncw * nrb;
@@ -789,6 +855,17 @@ hipError_t launch_la_init(const SelParams& p, hipStream_t s)
 hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, const double* prow, double* fac0, double* fac1,
                          double* rhsbuf, const DevState* st, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    if (update_streams(ld, R)) {
+        const int ncw = (ld + 127) / 128, nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
+        const int nblocks = (nunits + (UPDS_NT / 64) - 1) / (UPDS_NT / 64);
+        if (e0 && e1)
+            hipExtLaunchKernelGGL(lpx_update_s, dim3(nblocks), dim3(UPDS_NT), 0, s, e0, e1, 0,
+                                  T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        else
+            hipLaunchKernelGGL(lpx_update_s, dim3(nblocks), dim3(UPDS_NT), 0, s,
+                               T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        return hipGetLastError();
+    }
     const int ncw = (ld + 127) / 128;
     const int nrb = (R + UPD_ROWS - 1) / UPD_ROWS;
     const int nunits = ncw * nrb;

@@ -88,7 +88,9 @@ int LoopRun::begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o
                    lpx_pivot_cb cb, void* user)
 {
     c_ = c; o_ = *o; budget_ = budget; cb_ = cb; user_ = user;
-    enq_ = 0; fired_ = c.start_iter; status_ = LPX_RUNNING; init_phase_ = init.phase;
+    // pivots already made on this state: by another path (start_iter: resident hand-over) or by an earlier segment of the
+    // same run (init.iter: revised path continuing after a refactorisation) -- their callbacks have been fired
+    enq_ = 0; fired_ = init.iter > 0 ? init.iter : c.start_iter; status_ = LPX_RUNNING; init_phase_ = init.phase;
     std::memset(&local_, 0, sizeof(local_));
     batch_ = o_.batch > 0 ? o_.batch : 64;
     if (o_.profile && batch_ > 256) batch_ = 256;

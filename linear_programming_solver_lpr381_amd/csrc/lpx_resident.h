@@ -70,6 +70,23 @@ __device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
     return false;
 }
 
+// Abort flag of a resident launch (DevState::pad[1]), read past the L1 (sc1) like every other cross-workgroup word.
+__device__ __forceinline__ int rs_abort_raised(const DevState* st)
+{
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&st->pad[1]) : "memory");
+    return v;
+}
+// Diagnostic (LPX_RESIDENT_TEST_MUTE=3): a workgroup that gets its CU only after the others have given up -- it waits
+// for the abort flag and then runs as if nothing had happened.
+__device__ __forceinline__ void rs_wait_for_abort(const DevState* st)
+{
+    for (unsigned spin = 0; spin < 8u * RS_SPIN_MAX; ++spin) {
+        if (rs_abort_raised(st)) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // Block reductions of 1024-lane workgroups are slow when all 16 waves take part (four waves per SIMD take turns
 // through the same DPP chain, then all of them reduce the partials again: ~1 us).  The small vectors of this
 // kernel (objective row, ratios) are reduced by waves 0-3 only -- one per SIMD -- and the other waves just wait.

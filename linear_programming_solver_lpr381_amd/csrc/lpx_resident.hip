@@ -21,7 +21,9 @@
 // against any flag is needed.  Exchange buffers are double-buffered on the generation's parity: a workgroup can
 // run at most one exchange ahead of the slowest one (it needs that one's ratio to get the next pivot row).
 // Every wait is bounded (RS_SPIN_MAX polls); on expiry the workgroup raises the abort flag in the state
-// record and leaves without writing its rows back, and the host reports LPX_EDEVICE.
+// record and leaves without writing its rows back.  A workgroup that was scheduled late may still have finished a
+// short launch and written its rows, so the host keeps a copy of the tableau as it was when the launch started and
+// puts it back whenever the flag is up (lpx_tableau.cpp, run_resident); the streaming kernels continue from there.
 #include "lpx_resident.h"
 #include <cstdlib>
 
@@ -65,6 +67,10 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, w = blockIdx.x;
     if ((P.mute == 1 || (P.mute == 2 && st->iter > 0)) && w == (int)gridDim.x - 1) return;   // 2: from the second launch on
+    // A workgroup that starts after another one of this launch has given up cannot finish either: leave at once (the host
+    // restores the tableau of the launch's start whatever was written back, lpx_tableau.cpp run_resident).
+    if (rs_abort_raised(st)) return;
+    if (P.mute == 3 && w == (int)gridDim.x - 1) rs_wait_for_abort(st);                        // 3: a LATE workgroup
     const int ld = P.ld, C = P.C, m = P.R - 1, rpw = P.rpw;
     const int row0 = w * rpw;
     const int nloc = max(0, min(rpw, m - row0));

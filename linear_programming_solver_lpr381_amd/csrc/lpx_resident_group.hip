@@ -54,6 +54,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     DevState* st = N.st;
     if (st->status != LPX_RUNNING) return;
     if ((GP.mute == 1 || (GP.mute == 2 && st->iter > 0)) && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) return;   // plays dead
+    if (rs_abort_raised(st)) return;            // this node's launch is already lost (see lpx_resident.hip)
+    if (GP.mute == 3 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) rs_wait_for_abort(st);                      // a LATE workgroup
     const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
     const int C = P.C, m = P.R - 1, rhsc = C - 1;
     const int rpw = (m + G - 1) / G;

@@ -459,6 +459,9 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     hipMemsetAsync(r->aq, 0, sizeof(double) * r->ldat, s);
     hipMemsetAsync(r->fac, 0, sizeof(double) * (m + 1), s);
     hipMemsetAsync(r->rhsbuf, 0, sizeof(double) * (m + 1), s);
+    hipMemsetAsync(r->rc, 0, sizeof(double) * (n + m), s);          // nothing a fresh handle reads is left as hipMalloc found it
+    hipMemsetAsync(r->ws, 0, sizeof(double) * (m + 1), s);
+    hipMemsetAsync(r->trace, 0, sizeof(int32_t) * 2 * r->trace_cap, s);
     hipMemcpyAsync(Atmp, A, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, s);
     hipMemcpyAsync(r->c, c, sizeof(double) * n, hipMemcpyHostToDevice, s);
     hipLaunchKernelGGL(rv_transpose, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, s, Atmp, m, n, r->AT, r->ldat);

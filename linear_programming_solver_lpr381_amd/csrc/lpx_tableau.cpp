@@ -44,7 +44,8 @@ struct lpx_tableau {
     std::vector<hipEvent_t> events;
     // resident primal loop: exchange buffers (tagged granules) and the generation counter
     unsigned long long* xr = nullptr; unsigned long long* xp = nullptr; unsigned* xgen = nullptr;
-    int32_t* xbasis = nullptr;      // basis as it was before the first resident launch of a run
+    int32_t* xbasis = nullptr;      // basis as it was when the current resident launch started
+    double* xT = nullptr;           // tableau as it was when the current resident launch started (put back if the launch aborts)
     bool resident_off = false;      // a resident launch could not get its workgroups co-resident: stay on the streaming path
 };
 
@@ -178,7 +179,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     for (hipEvent_t e : t->events) hipEventDestroy(e);
     hipFree(t->T); hipFree(t->slab); hipFree(t->snapT); hipFree(t->snapBasis);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf);
-    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis);
+    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis); hipFree(t->xT);
     if (t->hslab) hipHostFree(t->hslab);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
     delete t;                       // the stream is borrowed (borrow_stream), not owned
@@ -370,6 +371,7 @@ static int resident_buffers(lpx_tableau* t)
     LPX_HIP_TRY(hipMalloc((void**)&t->xp, xp_bytes(t)));
     LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
     LPX_HIP_TRY(hipMalloc((void**)&t->xbasis, sizeof(int32_t) * (size_t)t->Rcap));
+    LPX_HIP_TRY(hipMalloc((void**)&t->xT, sizeof(double) * (size_t)t->Rcap * t->ld));
     LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, xr_bytes(t), t->stream));
     LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, xp_bytes(t), t->stream));
     LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
@@ -399,8 +401,11 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
     int fired = 0, status = LPX_RUNNING;
     for (long long launches = 0; status == LPX_RUNNING; ++launches) {
         if (launches > (long long)o->max_iter + 4) { set_error("resident loop: launch budget exhausted while still running"); return LPX_ITER_LIMIT; }
-        // basis as of the start of this launch: a launch that cannot finish writes nothing else back
+        // Tableau and basis as of the start of this launch.  A launch that cannot finish normally writes nothing back, but
+        // a workgroup that was scheduled late (after the others gave up) may complete a short launch and store its rows:
+        // whenever the abort flag is up the host puts this copy back, so the hand-over never sees a half-pivoted tableau.
         LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, t->stream));
+        LPX_HIP_TRY(hipMemcpyAsync(t->xT, t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, t->stream));
         if (o->profile) {
             while (t->events.size() < 2) { hipEvent_t e; LPX_HIP_TRY(hipEventCreate(&e)); t->events.push_back(e); }
             LPX_HIP_TRY(hipEventRecord(t->events[0], t->stream));
@@ -422,9 +427,10 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
             // completed launch.  Clear the exchange buffers so that no stale generation can ever match.
             resident_buffers_clear(t);
             set_error("resident loop: an exchange wait expired (workgroups not co-resident?)");
-            // Nothing of this launch was written back (a workgroup that cannot finish keeps every other one from
-            // finishing): the tableau is that of the previous launch; put its basis back and hand over to the
-            // streaming kernels, which continue from pivot `resume_iter`.
+            // Put the tableau and the basis of the launch's start back (late workgroups may have stored rows of a
+            // pivot the others never made) and hand over to the streaming kernels, which continue from pivot
+            // `resume_iter`.
+            LPX_HIP_TRY(hipMemcpy(t->T, t->xT, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice));
             LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
             t->resident_off = true;
             *resume_iter = fired;
@@ -527,13 +533,16 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     std::vector<int> live(count);
     for (int i = 0; i < count; ++i) live[i] = i;
     std::vector<int> fired(count, 0);
+    std::vector<DevState> before(count);
     long long launches = 0;
     while (!live.empty()) {
         const int n = (int)live.size() < slots ? (int)live.size() : slots;
         for (int k = 0; k < n; ++k) {
             g.h[k] = node[live[k]];
-            lpx_tableau* t = ts[live[k]];          // basis as of the start of this launch (a launch that cannot finish writes nothing else back)
+            lpx_tableau* t = ts[live[k]];          // tableau, basis and state as of the start of this launch (put back if it aborts)
+            before[live[k]] = g.hs[live[k]];
             LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
+            LPX_HIP_TRY(hipMemcpyAsync(t->xT, t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, g.stream));
         }
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
         LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
@@ -545,11 +554,15 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         if (aborted) {
             for (int k = 0; k < n; ++k) resident_buffers_clear(ts[live[k]]);
             set_error("resident group loop: an exchange wait expired (workgroups not co-resident?)");
-            // Nothing of this launch was written back: the nodes in it are as the previous launch left them (basis
-            // restored here); the caller finishes every unfinished node on the batched streaming kernels.
+            // A node whose launch aborted goes back to the state of the launch's start (tableau, basis, counters: a late
+            // workgroup may have stored rows of a pivot the others never made); the other nodes of the launch finished it
+            // normally and keep what they wrote.  The caller finishes every unfinished node on the streaming kernels.
             for (int k = 0; k < n; ++k) {
+                if (!g.hs[live[k]].pad[1]) continue;
                 lpx_tableau* t = ts[live[k]];
+                LPX_HIP_TRY(hipMemcpy(t->T, t->xT, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice));
                 LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
+                g.hs[live[k]] = before[live[k]];
                 g.hs[live[k]].pad[1] = 0;
             }
             for (int i = 0; i < count; ++i) statuses[i] = g.hs[i].status;      // LPX_RUNNING marks the unfinished ones

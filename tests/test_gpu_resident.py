@@ -288,3 +288,53 @@ def test_group_kernel_hands_over_to_the_streaming_kernels(oracle, mute):
     env = dict(os.environ, LPX_RESIDENT_TEST_MUTE=mute, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_late_workgroup_cannot_leave_a_half_pivoted_tableau(oracle):
+    """LPX_RESIDENT_TEST_MUTE=3: the last workgroup gets its CU only AFTER the others have given up (the real
+    non-co-residency case).  It still finds their first ratios, owns the pivot row, completes the only pivot of a
+    max_iter=1 launch and stores its rows -- a pivot the other workgroups never made.  The host must put the tableau
+    of the launch's start back before the streaming kernels take over (lpx_tableau.cpp run_resident /
+    run_resident_group): result bit-identical to the oracle, not a tableau with one row pivoted twice."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        from oracle import oracle as O
+        m, n = 8, 12
+        for seed in range(1, 400):                            # an LP whose first leaving row belongs to the LAST workgroup
+            c, A, b = synth.dense_lp(m, n, seed=seed)
+            T, basis = synth.primal_tableau_from(c, A, b)
+            Tr, br = T.copy(), basis.copy()
+            st, tr = O.primal_tableau(Tr, br, max_iter=1)
+            if len(tr) == 1 and tr[0][0] == m - 1:
+                break
+        else:
+            raise SystemExit("no suitable seed")
+        # primal resident kernel
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, s1 = dt.primal_run(max_iter=1)
+            Tg, bg = dt.download()
+            assert status == st == 3 and s1["pivots"] == 1 and dt.trace().tolist() == tr.tolist()
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+        # resident required: the launch is lost, the call fails, and the tableau is the one that went in
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            try:
+                dt.primal_run(max_iter=1, resident=1)
+                raise SystemExit("expected an error")
+            except L.LpxError as e:
+                assert e.code == L._lib.EDEVICE
+            Tg, bg = dt.download()
+            assert np.array_equal(Tg.view(np.uint64), T.view(np.uint64)) and bg.tolist() == basis.tolist()
+        # group kernel (one primal node through lpx_multi_run)
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            statuses, stats = L.multi_run([dt], [0], primal_opts=L.default_opts(False, max_iter=1))
+            Tg, bg = dt.download()
+            assert statuses[0] == 3 and stats[0]["pivots"] == 1, (statuses, stats)
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist()
+        print("OK")
+    ''')
+    env = dict(os.environ, LPX_RESIDENT_TEST_MUTE="3", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -131,3 +131,21 @@ def test_refactor_restores_exact_inverse(gpu, oracle):
     rc, ref = oracle.invert(np.ascontiguousarray(full[:, Bidx]))
     assert rc == 0 and np.array_equal(Binv.view(np.uint64), ref.view(np.uint64))     # same Invert, same bits
     assert np.allclose(xB1, xB0, rtol=1e-10, atol=1e-10) and abs(z1 - z0) <= 1e-10 * abs(z0)
+
+
+def test_refactor_segments_fire_each_pivot_callback_once(gpu, oracle):
+    """A run split into segments by the periodic refactorisation keeps ONE iteration count: the trace is not
+    restarted and every pivot's callback fires exactly once, in order (LoopRun::begin takes `init.iter` as the
+    number of callbacks already fired).  Round-1 record gpurun_out/t41.log was this path with the count reset
+    to 0 per segment."""
+    m, n, seed = 40, 64, 3
+    c, A, b = synth.dense_lp(m, n, seed=seed)
+    ref = oracle.revised_solve(oracle.Problem(oracle.MAX, c, A, np.zeros(m, np.int32), b))
+    ev = []
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.set_refactor(3)
+        status, st = rv.run(cb=lambda it, r, q: ev.append((it, r, q)), batch=2)
+        tr = rv.trace()
+    assert status == 0 and st["pivots"] == len(ref.trace) and tr.tolist() == ref.trace.tolist()
+    assert [e[0] for e in ev] == list(range(1, len(tr) + 1))
+    assert [[e[1], e[2]] for e in ev] == tr.tolist()

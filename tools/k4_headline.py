@@ -20,3 +20,11 @@ dt = L.DeviceTableau.from_host(T, basis)
 status, st = dt.primal_run(use_graph=0, batch=64, max_iter=600)
 print("cfg2 pivots", st["pivots"], "status", status)
 dt.close()
+# the bench's headline workload: real primal solve of the m=4096 n=8192 LP (tableau 4097x12289, 403 MB)
+c, A, b = synth.dense_lp(4096, 8192)
+T, basis = synth.primal_tableau_from(c, A, b)
+del A
+dt = L.DeviceTableau.from_host(T, basis)
+status, st = dt.primal_run(use_graph=0, batch=20, max_iter=npiv)
+print("lp-level pivots", st["pivots"], "status", status)
+dt.close()

@@ -22,8 +22,12 @@ for key in sorted(set(fetch) | set(write)):
     if "lpx_update" not in name and "lpx_resident" not in name:
         continue
     f = fetch.get(key, []); w = write.get(key, [])
-    # drop early-exit launches (no traffic)
-    f = [x for x in f if x > 16]; w = [x for x in w if x > 16]
+    # drop early-exit launches (tail of a batch after the loop has finished: they read the state record and leave)
+    def live(v):
+        if not v: return v
+        med = sorted(v)[len(v) // 2]
+        return [x for x in v if x > 16 and x >= 0.35 * med]
+    f = live(f); w = live(w)
     if not f or not w:
         continue
     fb = 2.0 * 1024.0 * sum(f) / len(f)        # doubled: gfx950 FETCH_SIZE under-count
