@@ -374,7 +374,9 @@ def main():
                           "iterations_per_s": s3["pivots"] / (s3["loop_ms"] * 1e-3),
                           "us_per_iteration": 1e3 * s3["loop_ms"] / max(s3["pivots"], 1),
                           "unfused_reference_bytes_per_iteration": 8.0 * (5 * 4096 ** 2 + 4096 * 8192),
-                          "engine_bytes_per_iteration": 8.0 * (4096 * 8192 + 4096 ** 2) + 16.0 * 4097 * 4097,
+                          "engine_bytes_per_iteration": 8.0 * 4096 * 8192 + 16.0 * 4097 * 4097,
+                          "engine_dataflow": "rv_price (A^T read once, nt) + rv_pick + rv_upd_ftran (W read+written once: the previous "
+                                             "pivot's rank-1 update fused with d = B^-1 a_q) + rv_select2; 4 launches per iteration",
                           "refactor_s": refac_s,
                           "refactor_algorithmic_gbs": 32.0 * 4096 ** 3 / refac_s / 1e9,
                           "refactor_note": "K7' = the reference's Invert (4096 Gauss-Jordan steps x 16*m*2m bytes), "

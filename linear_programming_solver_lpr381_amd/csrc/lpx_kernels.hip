@@ -323,12 +323,13 @@ static constexpr int UPDS_ROWS = 3;
 static constexpr size_t UPD_STREAM_BYTES = (size_t)320 << 20;
 
 typedef double lpx_d2 __attribute__((ext_vector_type(2)));
+// __builtin_nontemporal_load / _store lower to global_load_dwordx4 / global_store_dwordx4 ... nt on gfx950 and stay inside
+// hipcc's s_waitcnt bookkeeping (an inline-asm load would not: cdna_hip_programming.md 5.7).
 template <bool STREAM> __device__ __forceinline__ double2 upd_load(const double* p)
 {
     if constexpr (STREAM) {
-        lpx_d2 v;
-        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-        return make_double2(v.x, v.y);          // the caller waits (s_waitcnt vmcnt(0)) before the first use
+        const lpx_d2 v = __builtin_nontemporal_load(reinterpret_cast<const lpx_d2*>(p));
+        return make_double2(v.x, v.y);
     } else {
         return *reinterpret_cast<const double2*>(p);
     }
@@ -337,7 +338,7 @@ template <bool STREAM> __device__ __forceinline__ void upd_store(double* p, doub
 {
     if constexpr (STREAM) {
         lpx_d2 v; v.x = o.x; v.y = o.y;
-        asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+        __builtin_nontemporal_store(v, reinterpret_cast<lpx_d2*>(p));
     } else {
         *reinterpret_cast<double2*>(p) = o;
     }
@@ -385,7 +386,6 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
             f[k] = fac[i];
         }
     }
-    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
@@ -590,7 +590,6 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
             f[k] = fac[i];
         }
     }
-    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;

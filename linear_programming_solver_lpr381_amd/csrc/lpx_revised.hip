@@ -14,6 +14,7 @@
 #include "lpx_block.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 
@@ -27,6 +28,7 @@ struct RvParams {
     DevState* st;
     double eps, tol; int max_iter;
     double* ws; int rcap;
+    double* part_v; int32_t* part_k; int32_t* part_c; int nblk;     // per-workgroup entering candidates of rv_price
 };
 
 static constexpr int RV_NT = 1024;
@@ -207,6 +209,290 @@ __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused iteration (m <= RVF_MAXM): four launches instead of five and one pass less over W.
+//
+//   rv_price      r_N = c_N - pi N (MultiplyRow + Subtract, :71-72) with the entering candidate of :76-83 reduced on
+//                 the way: a workgroup sweeps rows of A^T (non-temporal loads -- A^T is 268 MB at config 3 and would
+//                 push W out of the Infinity Cache), each of its 8 waves owns a k-slice of pi in registers, and leaves
+//                 ONE (reduced cost, order key, column) candidate per workgroup.
+//   rv_pick       one workgroup: reduces the <= RVF_GRID candidates, copies the entering column (:95), iteration cap.
+//   rv_upd_ftran  d = B^-1 a_q (:96) fused with the PREVIOUS iteration's rank-1 update of W: a row of W is read once,
+//                 updated (same mul / sub per element as lpx_update), stored, and dotted with a_q in the same pass.  The
+//                 update of iteration k is therefore applied lazily by iteration k+1 ("pending", DevState::pad[2..3]);
+//                 lpx_revised_run and every accessor flush it (rv_flush) before W is looked at from outside.
+//   rv_select2    one workgroup: ratio test (:99-112), pivot row normalised in place, the (pi, z) row updated EAGERLY
+//                 (the next pricing needs it), x_B copy, basis bookkeeping (:121-124), pending := this pivot.
+//
+// Engine traffic per iteration: 8*m*n (A^T, read) + 16*m^2 (W, read + write) instead of 8*m*n + 24*m^2.
+// ------------------------------------------------------------------------------------------------
+static constexpr int RVF_NW = 8;                  // waves per workgroup
+static constexpr int RVF_NT = RVF_NW * 64;
+static constexpr int RVF_PER_MAX = 8;             // 1-KiB chunks of a row per wave held in registers (template: 1, 2, 4, 8)
+static constexpr int RVF_MAXLD = RVF_NW * RVF_PER_MAX * 128; // m <= 8192
+static constexpr int RVF_GRID = 2048;             // workgroups of rv_price (= candidates rv_pick reduces)
+typedef double rv_d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ Cand wave_cand_min(Cand c)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Cand o; o.v = __shfl_xor(c.v, d, 64); o.key = __shfl_xor(c.key, d, 64); o.col = __shfl_xor(c.col, d, 64);
+        c = cand_pick(c, o);
+    }
+    return c;
+}
+
+template <int RVF_PER>
+__global__ __launch_bounds__(RVF_NT) void rv_price(RvParams P)
+{
+    __shared__ double s_part[2][RVF_NW];
+    __shared__ double s_cv[RVF_NW];
+    __shared__ int s_ck[RVF_NW], s_cc[RVF_NW];
+    if (P.st->status != LPX_RUNNING) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m = P.m, n = P.n, ldat = P.ldat;
+    const double* __restrict__ pi = P.W + (size_t)m * P.ldw;
+    // chunk c of a row = doubles [128 c, 128 c + 128); wave w owns chunks w, w + NW, ...  (ldat is a multiple of 16 and A^T is
+    // zero beyond column m, so the tail of the last chunk multiplies zeros as long as it stays inside the row)
+    rv_d2 p[RVF_PER];
+#pragma unroll
+    for (int u = 0; u < RVF_PER; ++u) {
+        const int k = (wave + u * RVF_NW) * 128 + lane * 2;
+        p[u] = (k < m) ? *reinterpret_cast<const rv_d2*>(pi + k) : rv_d2{0.0, 0.0};
+        if (k + 1 >= m && k < m) p[u].y = 0.0;                      // pi[m] is z, not a price
+    }
+    Cand best; best.v = -P.eps; best.key = INT_MAX; best.col = -1;
+    for (int j0 = blockIdx.x * 2; j0 < n; j0 += gridDim.x * 2) {
+        const int ja = j0, jb = min(j0 + 1, n - 1);
+        const double* __restrict__ a0 = P.AT + (size_t)ja * ldat;
+        const double* __restrict__ a1 = P.AT + (size_t)jb * ldat;
+        rv_d2 x0[RVF_PER], x1[RVF_PER];
+#pragma unroll
+        for (int u = 0; u < RVF_PER; ++u) {
+            const int k = (wave + u * RVF_NW) * 128 + lane * 2;
+            if (k < ldat) {
+                x0[u] = __builtin_nontemporal_load(reinterpret_cast<const rv_d2*>(a0 + k));
+                x1[u] = __builtin_nontemporal_load(reinterpret_cast<const rv_d2*>(a1 + k));
+            } else { x0[u] = rv_d2{0.0, 0.0}; x1[u] = rv_d2{0.0, 0.0}; }
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RVF_PER; ++u) {
+            s0 += x0[u].x * p[u].x; s0 += x0[u].y * p[u].y;
+            s1 += x1[u].x * p[u].x; s1 += x1[u].y * p[u].y;
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        if (lane == 0) { s_part[0][wave] = s0; s_part[1][wave] = s1; }
+        __syncthreads();
+        if (threadIdx.x < 2 && j0 + (int)threadIdx.x < n) {
+            const int j = j0 + threadIdx.x;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < RVF_NW; ++w) t += s_part[threadIdx.x][w];
+            const int key = P.key[j];
+            const double rcj = key >= 0 ? P.c[j] - t : __builtin_inf();
+            P.rc[j] = rcj;
+            if (key >= 0 && rcj < -P.eps) { Cand c; c.v = rcj; c.key = key; c.col = j; best = cand_pick(best, c); }
+        }
+        __syncthreads();
+    }
+    // slack columns: r_s = 0 - pi_s (their column of [A | I] is a unit vector); spread over the first workgroups
+    const int s = blockIdx.x * RVF_NT + threadIdx.x;
+    const bool has_slack = blockIdx.x * RVF_NT < m;                 // uniform per workgroup
+    if (has_slack && s < m) {
+        const int key = P.key[n + s];
+        const double rs = key >= 0 ? 0.0 - pi[s] : __builtin_inf();
+        P.rc[n + s] = rs;
+        if (key >= 0 && rs < -P.eps) { Cand c; c.v = rs; c.key = key; c.col = n + s; best = cand_pick(best, c); }
+    }
+    // workgroup candidate: lanes 0,1 of wave 0 hold the structural ones, every lane possibly a slack one
+    if (has_slack) {
+        best = wave_cand_min(best);
+        if (lane == 0) { s_cv[wave] = best.v; s_ck[wave] = best.key; s_cc[wave] = best.col; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Cand w; w.v = s_cv[0]; w.key = s_ck[0]; w.col = s_cc[0];
+#pragma unroll
+            for (int k = 1; k < RVF_NW; ++k) { Cand o; o.v = s_cv[k]; o.key = s_ck[k]; o.col = s_cc[k]; w = cand_pick(w, o); }
+            P.part_v[blockIdx.x] = w.v; P.part_k[blockIdx.x] = w.key; P.part_c[blockIdx.x] = w.col;
+        }
+    } else if (wave == 0) {
+        Cand o; o.v = __shfl(best.v, 1, 64); o.key = __shfl(best.key, 1, 64); o.col = __shfl(best.col, 1, 64);
+        best = cand_pick(best, o);
+        if (lane == 0) { P.part_v[blockIdx.x] = best.v; P.part_k[blockIdx.x] = best.key; P.part_c[blockIdx.x] = best.col; }
+    }
+}
+
+// entering variable from the workgroup candidates (:76-92), dense copy of its column (:95), objective-row factor
+__global__ __launch_bounds__(RV_NT) void rv_pick(RvParams P)
+{
+    __shared__ double s_v[RV_NW];
+    __shared__ int s_k[RV_NW];
+    __shared__ int s_c[RV_NW];
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (st->iter >= P.max_iter) {                       // :66 / :144
+        if (t == 0) { st->status = LPX_ITER_LIMIT; st->r = -1; }
+        return;
+    }
+    Cand best; best.v = -P.eps; best.key = INT_MAX; best.col = -1;
+    for (int b = t; b < P.nblk; b += RV_NT) {
+        Cand c; c.v = P.part_v[b]; c.key = P.part_k[b]; c.col = P.part_c[b];
+        if (c.col >= 0) best = cand_pick(best, c);
+    }
+    best = wave_cand_min(best);
+    if (lane == 0) { s_v[wave] = best.v; s_k[wave] = best.key; s_c[wave] = best.col; }
+    __syncthreads();
+    Cand w; w.v = s_v[lane & (RV_NW - 1)]; w.key = s_k[lane & (RV_NW - 1)]; w.col = s_c[lane & (RV_NW - 1)];
+    w = wave_cand_min(w);
+    const int q = w.col;
+    if (q < 0) {                                        // :84-90
+        if (t == 0) { st->status = LPX_OPTIMAL; st->r = -1; st->q = -1; }
+        return;
+    }
+    for (int k = t; k < P.ldw; k += RV_NT)              // aq has ldw entries; zero from m on
+        P.aq[k] = (k >= P.m) ? 0.0 : ((q < P.n) ? P.AT[(size_t)q * P.ldat + k] : ((k == q - P.n) ? 1.0 : 0.0));
+    if (t == 0) { st->q = q; P.fac[P.m] = -w.v; }       // pi.a_q - c_q = -(reduced cost)
+}
+
+// d = B^-1 a_q fused with the pending rank-1 update of the previous pivot (see the section comment).
+// pad[2] = 1: rows i != pad[3] of W (i < m) still have to become  W[i,:] - fac[i] * prow[:]  (fac = previous d).
+template <int RVF_PER>
+__global__ __launch_bounds__(RVF_NT) void rv_upd_ftran(RvParams P)
+{
+    __shared__ double s_part[RVF_NW];
+    const DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m = P.m, ldw = P.ldw;
+    const bool pending = st->pad[2] != 0;
+    const int rp = st->pad[3];
+    constexpr int cover = RVF_NW * RVF_PER * 128;       // >= m (launcher); columns [cover, ldw) are the tail below
+    rv_d2 a[RVF_PER], p[RVF_PER];
+#pragma unroll
+    for (int u = 0; u < RVF_PER; ++u) {
+        const int k = (wave + u * RVF_NW) * 128 + lane * 2;
+        a[u] = rv_d2{0.0, 0.0}; p[u] = rv_d2{0.0, 0.0};
+        if (k < ldw) a[u] = *reinterpret_cast<const rv_d2*>(P.aq + k);            // a_q is zero from m on (rv_pick): column m (x_B) stays out of the dot
+        if (pending && k < ldw) p[u] = *reinterpret_cast<const rv_d2*>(P.prow + k);
+    }
+    for (int i = blockIdx.x; i < m; i += gridDim.x) {
+        double* __restrict__ w = P.W + (size_t)i * ldw;
+        const bool upd = pending && i != rp;
+        const double f = upd ? P.fac[i] : 0.0;
+        rv_d2 x[RVF_PER];
+#pragma unroll
+        for (int u = 0; u < RVF_PER; ++u) {
+            const int k = (wave + u * RVF_NW) * 128 + lane * 2;
+            x[u] = (k < ldw) ? *reinterpret_cast<const rv_d2*>(w + k) : rv_d2{0.0, 0.0};
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < RVF_PER; ++u) {
+            const int k = (wave + u * RVF_NW) * 128 + lane * 2;
+            if (upd && k < ldw) {
+                x[u].x = x[u].x - f * p[u].x;            // mul, then sub -- the arithmetic of lpx_update
+                x[u].y = x[u].y - f * p[u].y;
+                *reinterpret_cast<rv_d2*>(w + k) = x[u];
+            }
+            s += x[u].x * a[u].x; s += x[u].y * a[u].y;
+            if (k <= m && m < k + 2) P.rhsbuf[i] = (m == k) ? x[u].x : x[u].y;      // x_B[i] = W[i, m] (one lane of the workgroup)
+        }
+        // columns beyond the chunks (m a multiple of NW*128: the x_B column and its padding, <= 16 doubles); no part in the dot
+        if (cover < ldw && (int)threadIdx.x < (ldw - cover) / 2) {
+            const int k = cover + 2 * threadIdx.x;
+            rv_d2 y = *reinterpret_cast<const rv_d2*>(w + k);
+            if (upd) {
+                const rv_d2 pt = *reinterpret_cast<const rv_d2*>(P.prow + k);
+                y.x = y.x - f * pt.x; y.y = y.y - f * pt.y;
+                *reinterpret_cast<rv_d2*>(w + k) = y;
+            }
+            if (k <= m && m < k + 2) P.rhsbuf[i] = (m == k) ? y.x : y.y;
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_part[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < RVF_NW; ++k) t += s_part[k];
+            P.fac[i] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// Ratio test (:99-112, hysteresis 1e-12), pivot row normalised in place, (pi, z) row updated eagerly, bookkeeping (:121-124).
+__global__ __launch_bounds__(SEL_NT) void rv_select2(RvParams P)
+{
+    DevState* st = P.st;
+    if (st->status != LPX_RUNNING) return;
+    const int t = threadIdx.x;
+    const int m = P.m;
+    const int iter = st->iter;
+    const int q = st->q;
+    const int r = block_hysteresis_segments<SEL_NW>(m, P.tol, RowRatio{P.fac, 1, P.rhsbuf, 1, P.eps});
+    if (r < 0) {                                                    // :113-118
+        if (t == 0) { st->status = LPX_UNBOUNDED; st->r = -1; }
+        return;
+    }
+    const double piv = P.fac[r];
+    const double fm = P.fac[m];
+    double* wrow = P.W + (size_t)r * P.ldw;
+    double* prw = P.W + (size_t)m * P.ldw;
+    const int C = m + 1;
+    __syncthreads();
+    for (int j = t; j < C; j += SEL_NT) {
+        const double p = wrow[j] / piv;                             // true division, as the tableau path
+        wrow[j] = p;
+        P.prow[j] = p;
+        const double o = prw[j] - fm * p;                           // the (pi, z) row NOW: the next pricing reads it
+        prw[j] = o;
+        if (j == m) { P.rhsbuf[r] = p; P.rhsbuf[m] = o; }
+    }
+    for (int j = C + t; j < P.ldw; j += SEL_NT) P.prow[j] = 0.0;
+    if (t == 0) {
+        const int leaving = P.Bidx[r];                              // :121-124
+        P.Bidx[r] = q;
+        P.key[q] = -1;
+        P.key[leaving] = st->pad[0];
+        st->pad[0] = st->pad[0] + 1;
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        st->iter = iter + 1;
+        st->r = r; st->qn = -1;
+        st->pad[2] = 1; st->pad[3] = r;                             // pending: rows i != r, i < m
+    }
+}
+
+// applies the pending update (if any) to W: the tableau path's tile, rows i < m, i != pad[3]
+__global__ __launch_bounds__(256) void rv_flush(RvParams P, int ncw, int nunits)
+{
+    const DevState* st = P.st;
+    if (st->pad[2] == 0) return;
+    const int rp = st->pad[3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= nunits) return;
+    const int cw = unit % ncw, rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    if (col >= P.ldw) return;
+    const rv_d2 p = *reinterpret_cast<const rv_d2*>(P.prow + col);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = rb * 8 + k;
+        if (i < P.m && i != rp) {
+            double* w = P.W + (size_t)i * P.ldw + col;
+            rv_d2 v = *reinterpret_cast<const rv_d2*>(w);
+            const double f = P.fac[i];
+            v.x = v.x - f * p.x; v.y = v.y - f * p.y;
+            *reinterpret_cast<rv_d2*>(w) = v;
+        }
+    }
+}
+__global__ void rv_clear_pending(DevState* st) { st->pad[2] = 0; }
+
+// ------------------------------------------------------------------------------------------------
 // K7': Invert (Models/RevisedPrimalSimplex.cs:402-456) on the device, bit for bit: Gauss-Jordan on the
 // augmented [M | I] (n x 2n) with partial pivoting -- first maximum of |a| on ties (:419-425), singular if
 // |pivot| < 1e-9 (:426), row swap (:428-434), scaling by true division (:437-438), elimination of every
@@ -377,6 +663,8 @@ struct lpx_revised {
     double* b = nullptr;            // right-hand sides (refactorisation)
     double* Mb = nullptr;           // m x m basis matrix scratch
     InvWork* inv = nullptr; int refactor_every = 0;
+    double* part_v = nullptr; int32_t* part_k = nullptr; int32_t* part_c = nullptr;   // candidates of rv_price
+    bool fused = false;             // four-launch iteration with the lazily applied W update (rows of W fit RVF_MAXLD)
     DevState* st = nullptr; DevState* hst = nullptr;
     hipStream_t stream = nullptr;
     hipGraphExec_t gexec = nullptr; int g_batch = 0; std::string g_key;
@@ -392,11 +680,42 @@ static RvParams rv_params(lpx_revised* r, const lpx_run_opts* o)
     p.rc = r->rc; p.aq = r->aq; p.Bidx = r->Bidx; p.key = r->key; p.trace = r->trace; p.trace_cap = r->trace_cap;
     p.st = r->st; p.eps = o->eps; p.tol = o->ratio_tol; p.max_iter = o->max_iter;
     p.ws = r->ws; p.rcap = 0;
+    p.part_v = r->part_v; p.part_k = r->part_k; p.part_c = r->part_c;
+    p.nblk = std::min(RVF_GRID, std::max((r->n + 1) / 2, (r->m + RVF_NT - 1) / RVF_NT));
     return p;
+}
+
+template <int PER> static void rv_launch_fused(const RvParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(rv_price<PER>, dim3(p.nblk), dim3(RVF_NT), 0, s, p);
+    hipLaunchKernelGGL(rv_pick, dim3(1), dim3(RV_NT), 0, s, p);
+    hipLaunchKernelGGL(rv_upd_ftran<PER>, dim3(std::min(p.m, 4 * RVF_GRID)), dim3(RVF_NT), 0, s, p);
+    hipLaunchKernelGGL(rv_select2, dim3(1), dim3(SEL_NT), 0, s, p);
+}
+
+// applies the pending W update, if there is one (fused path); stream-ordered, then waits
+static int rv_flush_pending(lpx_revised* r)
+{
+    if (!r->fused) return 0;
+    lpx_run_opts od; lpx_default_opts(&od, 1);
+    RvParams p = rv_params(r, &od);
+    const int ncw = (p.ldw + 127) / 128, nunits = ncw * ((p.m + 7) / 8);
+    hipLaunchKernelGGL(rv_flush, dim3((nunits + 3) / 4), dim3(256), 0, r->stream, p, ncw, nunits);
+    hipLaunchKernelGGL(rv_clear_pending, dim3(1), dim3(1), 0, r->stream, r->st);
+    LPX_HIP_TRY(hipGetLastError());
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    return 0;
 }
 
 static int rv_enqueue(lpx_revised* r, const RvParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    if (r->fused) {
+        const int chunks = (p.m + 127) / 128, per = (chunks + RVF_NW - 1) / RVF_NW;     // chunks cover [0, m); see rv_upd_ftran's tail
+        if (per <= 1) rv_launch_fused<1>(p, s); else if (per <= 2) rv_launch_fused<2>(p, s);
+        else if (per <= 4) rv_launch_fused<4>(p, s); else rv_launch_fused<8>(p, s);
+        LPX_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(rv_price_dot, dim3((p.n + 3) / 4), dim3(256), 0, s, p);
     hipLaunchKernelGGL(rv_price_pick, dim3(1), dim3(RV_NT), 0, s, p);
     hipLaunchKernelGGL(rv_ftran, dim3((p.m + 3) / 4), dim3(256), 0, s, p);
@@ -416,7 +735,7 @@ void lpx_revised_destroy(lpx_revised* r)
     for (hipEvent_t e : r->events) hipEventDestroy(e);
     hipFree(r->AT); hipFree(r->c); hipFree(r->W); hipFree(r->prow); hipFree(r->fac); hipFree(r->rhsbuf);
     hipFree(r->rc); hipFree(r->aq); hipFree(r->ws); hipFree(r->Bidx); hipFree(r->key); hipFree(r->trace);
-    hipFree(r->st); hipFree(r->b); hipFree(r->Mb);
+    hipFree(r->st); hipFree(r->b); hipFree(r->Mb); hipFree(r->part_v); hipFree(r->part_k); hipFree(r->part_c);
     delete r->inv;
     if (r->hst) hipHostFree(r->hst);
     delete r;
@@ -441,7 +760,12 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     RALLOC(r->AT, atb); RALLOC(r->c, sizeof(double) * n); RALLOC(r->W, wb);
     RALLOC(r->prow, sizeof(double) * r->ldw); RALLOC(r->fac, sizeof(double) * (m + 1));
     RALLOC(r->rhsbuf, sizeof(double) * (m + 1)); RALLOC(r->rc, sizeof(double) * (n + m));
-    RALLOC(r->aq, sizeof(double) * r->ldat); RALLOC(r->ws, sizeof(double) * (m + 1));
+    RALLOC(r->aq, sizeof(double) * r->ldw); RALLOC(r->ws, sizeof(double) * (m + 1));
+    RALLOC(r->part_v, sizeof(double) * RVF_GRID); RALLOC(r->part_k, sizeof(int32_t) * RVF_GRID); RALLOC(r->part_c, sizeof(int32_t) * RVF_GRID);
+    {   // LPX_REVISED_FUSED=0: the five-launch iteration with the eager W update (also the path of rows longer than RVF_MAXLD)
+        static const bool fused_env = [] { const char* e = std::getenv("LPX_REVISED_FUSED"); return !(e && e[0] == '0'); }();
+        r->fused = fused_env && m <= RVF_MAXLD;
+    }
     RALLOC(r->Bidx, sizeof(int32_t) * m); RALLOC(r->key, sizeof(int32_t) * (n + m));
     RALLOC(r->trace, sizeof(int32_t) * 2 * r->trace_cap); RALLOC(r->st, sizeof(DevState));
     RALLOC(Atmp, sizeof(double) * (size_t)m * n);
@@ -456,7 +780,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     hipMemsetAsync(r->AT, 0, atb, s);
     hipMemsetAsync(r->W, 0, wb, s);
     hipMemsetAsync(r->prow, 0, sizeof(double) * r->ldw, s);
-    hipMemsetAsync(r->aq, 0, sizeof(double) * r->ldat, s);
+    hipMemsetAsync(r->aq, 0, sizeof(double) * r->ldw, s);
     hipMemsetAsync(r->fac, 0, sizeof(double) * (m + 1), s);
     hipMemsetAsync(r->rhsbuf, 0, sizeof(double) * (m + 1), s);
     hipMemsetAsync(r->rc, 0, sizeof(double) * (n + m), s);          // nothing a fresh handle reads is left as hipMalloc found it
@@ -492,6 +816,8 @@ int lpx_revised_refactor(lpx_revised* r)
     if (!r) { set_error("lpx_revised_refactor: null handle"); return LPX_EINVAL; }
     const int m = r->m;
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    // W is rebuilt from the basis: a rank-1 update still pending on the old W is dropped, not applied
+    if (r->fused) { hipLaunchKernelGGL(rv_clear_pending, dim3(1), dim3(1), 0, r->stream, r->st); LPX_HIP_TRY(hipStreamSynchronize(r->stream)); }
     if (!r->inv) {
         r->inv = new InvWork();
         int rc = inv_alloc(*r->inv, m);
@@ -526,7 +852,11 @@ int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void
 {
     if (!r) { set_error("lpx_revised_run: null handle"); return LPX_EINVAL; }
     lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
-    if (r->refactor_every <= 0) return revised_run_segment(r, o, cb, user, st, 0);
+    if (r->refactor_every <= 0) {
+        const int status = revised_run_segment(r, o, cb, user, st, 0);
+        const int rc = rv_flush_pending(r);             // W as the last pivot left it, before anyone looks at it
+        return rc ? rc : status;
+    }
     // segments of `refactor_every` iterations, B^-1 recomputed from the basis in between (K7')
     lpx_stats total; std::memset(&total, 0, sizeof(total));
     int done = 0, status = LPX_ITER_LIMIT;
@@ -540,10 +870,11 @@ int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void
         if (status != LPX_ITER_LIMIT) break;
         done = (int)s1.pivots;
         if (done >= o->max_iter) break;
-        int rc = lpx_revised_refactor(r);
+        int rc = lpx_revised_refactor(r);               // drops the pending update: W is rebuilt from the basis
         if (rc) return rc;
     }
     if (st) { double h = st->h2d_ms, dd = st->d2h_ms; *st = total; st->h2d_ms = h; st->d2h_ms = dd; }
+    { const int rc = rv_flush_pending(r); if (rc) return rc; }
     return status;
 }
 
@@ -555,7 +886,7 @@ static int revised_run_segment(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_
     c.events = &r->events; c.gexec = &r->gexec; c.g_batch = &r->g_batch; c.g_key = &r->g_key;
     c.key.assign(reinterpret_cast<const char*>(&p), sizeof(p));
     c.enqueue_iter = [r, p](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { return rv_enqueue(r, p, s, e0, e1); };
-    c.launches_per_iter = 5;
+    c.launches_per_iter = r->fused ? 4 : 5;
     c.profile_maps = true;
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
@@ -591,6 +922,7 @@ int lpx_revised_result(lpx_revised* r, int32_t* Bidx, int32_t* Nidx, double* xB,
     if (!r) return LPX_EINVAL;
     const int m = r->m, n = r->n;
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    { const int rc = rv_flush_pending(r); if (rc) return rc; }
     if (Bidx) LPX_HIP_TRY(hipMemcpy(Bidx, r->Bidx, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
     if (xB) LPX_HIP_TRY(hipMemcpy2D(xB, sizeof(double), r->W + m, sizeof(double) * r->ldw, sizeof(double), m, hipMemcpyDeviceToHost));
     if (z) LPX_HIP_TRY(hipMemcpy(z, r->W + (size_t)m * r->ldw + m, sizeof(double), hipMemcpyDeviceToHost));
@@ -609,6 +941,7 @@ int lpx_revised_binv(lpx_revised* r, double* Binv)
 {
     if (!r || !Binv) return LPX_EINVAL;
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    { const int rc = rv_flush_pending(r); if (rc) return rc; }
     LPX_HIP_TRY(hipMemcpy2D(Binv, sizeof(double) * r->m, r->W, sizeof(double) * r->ldw, sizeof(double) * r->m, r->m, hipMemcpyDeviceToHost));
     return 0;
 }
