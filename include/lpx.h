@@ -204,9 +204,24 @@ int  lpx_revised_binv(lpx_revised* r, double* Binv /* [m*m] row-major */);
 int  lpx_revised_iteration_view(lpx_revised* r, double* rc, double* d);
 /* K7': recompute [[B^-1, x_B], [c_B B^-1, z]] from the current basis with the device Gauss-Jordan below
  * (what the reference does every iteration, :128-133).  lpx_revised_set_refactor(r, k) makes
- * lpx_revised_run do it after every k iterations (0 = never, the default). */
+ * lpx_revised_run do it after every k iterations (0 = only when the drift policy below asks for it, the default). */
 int  lpx_revised_refactor(lpx_revised* r);
 int  lpx_revised_set_refactor(lpx_revised* r, int every);
+/* How lpx_revised_refactor rebuilds B^-1.  0 (default) = the reference's Invert on the device, bit for bit (:402-456).
+ * 1 = fast: Newton-Schulz refinement X <- X + X (I - B X) of the maintained inverse, two dense m x m x m contractions on the
+ * FP64 matrix cores (v_mfma_f64_16x16x4_f64); it rounds differently from Invert (bar: same pivots, z within 1e-9,
+ * |B^-1 B - I| <= 1e-9) and falls back to mode 0 by itself when the maintained inverse is too far off to contract. */
+int  lpx_revised_set_refactor_mode(lpx_revised* r, int mode);
+/* Drift control of the product-form inverse (the reference never drifts: it re-inverts every iteration).  Every
+ * `check_every` iterations lpx_revised_run evaluates rho = max_i |(B x_B)_i - b_i| / (1 + max_i |b_i|) on the device (one
+ * m x m sweep) and refactorises when rho > tol.  Default: check_every = 256, tol = 1e-9; check_every = 0 switches it off.
+ * lpx_revised_set_refactor(r, k > 0) replaces it by an unconditional refactorisation every k iterations. */
+int  lpx_revised_set_drift_policy(lpx_revised* r, int check_every, double tol);
+int  lpx_revised_residual(lpx_revised* r, double* rel /* rho */, double* abs_ /* max_i |(B x_B)_i - b_i| */);
+/* Counters since creation; gemm_ms / gemm_calls: HIP-event time and number of the matrix-core contractions (2 m^3 flop each)
+ * of the LAST fast refactorisation.  Any pointer may be NULL. */
+int  lpx_revised_refactor_stats(lpx_revised* r, int* refactors, int* fast_steps, int* fast_fallbacks, double* last_residual,
+                                double* gemm_ms, int* gemm_calls);
 /* Invert (Models/RevisedPrimalSimplex.cs:402-456), bit for bit: Gauss-Jordan with partial pivoting on
  * [M | I]; M and inv are n x n row-major host buffers.  Returns 0 or LPX_E_SINGULAR (:426). */
 int  lpx_invert(const double* M, int n, double* inv);

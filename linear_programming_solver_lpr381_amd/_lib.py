@@ -138,6 +138,10 @@ def lib() -> C.CDLL:
     L.lpx_sensitivity_shadow_prices.argtypes = _sens + [C.c_char_p, C.c_int]
     L.lpx_sensitivity_solve_duality.argtypes = _sens + [C.POINTER(SolveOpts), C.POINTER(Result)]
     L.lpx_revised_refactor.argtypes = [vp]
+    L.lpx_revised_set_refactor_mode.argtypes = [vp, C.c_int]
+    L.lpx_revised_set_drift_policy.argtypes = [vp, C.c_int, C.c_double]
+    L.lpx_revised_residual.argtypes = [vp, dp, dp]
+    L.lpx_revised_refactor_stats.argtypes = [vp, ip, ip, ip, dp, dp, ip]
     L.lpx_revised_set_refactor.argtypes = [vp, C.c_int]
     L.lpx_invert.argtypes = [dp, C.c_int, dp]
     L.lpx_revised_trace.argtypes = [vp, ip, C.c_int, C.POINTER(C.c_int)]

@@ -73,6 +73,9 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs,
                              int32_t* basis, hipStream_t s);
 hipError_t kernels_init();          // one-time function attributes
+// FP64 matrix-core GEMM (lpx_mfma.hip): C = I - A*B (mode 0, max |C_ij| -> *absmax as double bits) or C = D + A*B (mode 1)
+hipError_t launch_dgemm_mfma(const double* A, int lda, const double* B, int ldb, double* C, int ldc, const double* D, int ldd,
+                             int M, int N, int K, int mode, unsigned long long* absmax, hipStream_t s);
 // resident group loop (lpx_resident_group.hip): one entry per node of a launch
 struct ResNode {
     double* T; int ld, R, C;

@@ -592,6 +592,82 @@ __global__ __launch_bounds__(256) void rv_refill_pi(RvParams P, const double* __
     if (j == P.m) P.rhsbuf[P.m] = s;
 }
 
+// ---- drift control -------------------------------------------------------------------------------------------
+// Cheap residual of the maintained inverse: rho = max_i |(B x_B)_i - b_i| / (1 + max_i |b_i|) with x_B the last column of W.
+// B x_B = sum_k x_B[k] * column Bidx[k] of [A | I]; columns are rows of A^T, so thread i of a workgroup reads A^T[col][i]
+// coalesced; the k range is split over blockIdx.y and the slices meet in a [KS][m] buffer (fixed order: deterministic).
+static constexpr int RVR_KS = 32;
+__global__ __launch_bounds__(256) void rv_resid_partial(RvParams P, double* __restrict__ part)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = (P.m + RVR_KS - 1) / RVR_KS;
+    const int k0 = blockIdx.y * per, k1 = min(P.m, k0 + per);
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) {
+        const int col = P.Bidx[k];
+        const double xk = P.W[(size_t)k * P.ldw + P.m];
+        if (i < P.m) acc += (col < P.n) ? P.AT[(size_t)col * P.ldat + i] * xk : ((i == col - P.n) ? xk : 0.0);
+    }
+    if (i < P.m) part[(size_t)blockIdx.y * P.m + i] = acc;
+}
+__global__ __launch_bounds__(1024) void rv_resid_final(RvParams P, const double* __restrict__ part, const double* __restrict__ b, double* out)
+{
+    __shared__ double s_a[16], s_b[16];
+    double e = 0.0, bm = 0.0;
+    for (int i = threadIdx.x; i < P.m; i += 1024) {
+        double y = 0.0;
+        for (int k = 0; k < RVR_KS; ++k) y += part[(size_t)k * P.m + i];
+        e = fmax(e, fabs(y - b[i])); bm = fmax(bm, fabs(b[i]));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { e = fmax(e, __shfl_xor(e, d, 64)); bm = fmax(bm, __shfl_xor(bm, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = e; s_b[threadIdx.x >> 6] = bm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) { e = fmax(e, s_a[k]); bm = fmax(bm, s_b[k]); }
+        out[0] = e / (1.0 + bm); out[1] = e;
+    }
+}
+
+// fast refactorisation (Newton-Schulz on the matrix cores, lpx_mfma.hip): x_B = B^-1 b and (pi, z) = c_B [B^-1, x_B] from W in place
+__global__ __launch_bounds__(256) void rv_refill_xb(RvParams P, const double* __restrict__ b)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.m) return;
+    const double s = wave_dot(P.W + (size_t)i * P.ldw, b, P.m, lane);
+    if (lane == 0) { P.W[(size_t)i * P.ldw + P.m] = s; P.rhsbuf[i] = s; }
+}
+static constexpr int RVP_RS = 16;
+__global__ __launch_bounds__(256) void rv_refill_pi_partial(RvParams P, const double* __restrict__ call, double* __restrict__ part)
+{
+    // part[y][j] = sum over row slice y of cB_i * W[i][j], j <= m (column m gives z); 64 columns x 4 row groups per workgroup
+    __shared__ double s_p[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const int per = (P.m + RVP_RS - 1) / RVP_RS;
+    const int i0 = blockIdx.y * per, i1 = min(P.m, i0 + per);
+    double acc = 0.0;
+    if (j <= P.m)
+        for (int i = i0 + g; i < i1; i += 4) {
+            const int col = P.Bidx[i];
+            const double cb = col < P.n ? call[col] : 0.0;
+            acc += cb * P.W[(size_t)i * P.ldw + j];
+        }
+    s_p[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && j <= P.m) part[(size_t)blockIdx.y * P.ldw + j] = (s_p[0][c] + s_p[1][c]) + (s_p[2][c] + s_p[3][c]);
+}
+__global__ __launch_bounds__(256) void rv_refill_pi_final(RvParams P, const double* __restrict__ part)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > P.m) return;
+    double s = 0.0;
+    for (int y = 0; y < RVP_RS; ++y) s += part[(size_t)y * P.ldw + j];
+    P.W[(size_t)P.m * P.ldw + j] = s;
+    if (j == P.m) P.rhsbuf[P.m] = s;
+}
+
 }  // namespace lpx
 
 // ---------------------------------------------------------------------------------------------------
@@ -664,6 +740,13 @@ struct lpx_revised {
     double* Mb = nullptr;           // m x m basis matrix scratch
     InvWork* inv = nullptr; int refactor_every = 0;
     double* part_v = nullptr; int32_t* part_k = nullptr; int32_t* part_c = nullptr;   // candidates of rv_price
+    int refactor_mode = 0;          // 0 = exact Gauss-Jordan (the reference's Invert, bit for bit), 1 = Newton-Schulz on the matrix cores
+    int drift_every = 256; double drift_tol = 1e-9;    // residual check of the maintained inverse (0 = off)
+    double last_residual = -1.0; int refactors = 0, fast_steps = 0, fast_fallbacks = 0;
+    double gemm_ms = 0.0; int gemm_calls = 0;       // HIP-event time of the matrix-core contractions of the last fast refactorisation
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *nsR = nullptr, *nsX = nullptr, *scratch = nullptr; unsigned long long* nsmax = nullptr; double* resid = nullptr;
+    int ldp = 0;                    // leading dimension of the m x m scratch matrices (Mb, nsR)
     bool fused = false;             // four-launch iteration with the lazily applied W update (rows of W fit RVF_MAXLD)
     DevState* st = nullptr; DevState* hst = nullptr;
     hipStream_t stream = nullptr;
@@ -733,8 +816,11 @@ void lpx_revised_destroy(lpx_revised* r)
     if (r->stream) hipStreamSynchronize(r->stream);
     if (r->gexec) hipGraphExecDestroy(r->gexec);
     for (hipEvent_t e : r->events) hipEventDestroy(e);
+    if (r->ev0) hipEventDestroy(r->ev0);
+    if (r->ev1) hipEventDestroy(r->ev1);
     hipFree(r->AT); hipFree(r->c); hipFree(r->W); hipFree(r->prow); hipFree(r->fac); hipFree(r->rhsbuf);
     hipFree(r->rc); hipFree(r->aq); hipFree(r->ws); hipFree(r->Bidx); hipFree(r->key); hipFree(r->trace);
+    hipFree(r->nsR); hipFree(r->nsX); hipFree(r->scratch); hipFree(r->nsmax); hipFree(r->resid);
     hipFree(r->st); hipFree(r->b); hipFree(r->Mb); hipFree(r->part_v); hipFree(r->part_k); hipFree(r->part_c);
     delete r->inv;
     if (r->hst) hipHostFree(r->hst);
@@ -750,6 +836,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     r->m = m; r->n = n;
     r->ldat = (m + 15) / 16 * 16;
     r->ldw = (m + 1 + 15) / 16 * 16;
+    r->ldp = (m + 15) / 16 * 16;
     const size_t atb = sizeof(double) * (size_t)n * r->ldat;
     const size_t wb = sizeof(double) * (size_t)(m + 1) * r->ldw;
     double* Atmp = nullptr;
@@ -811,24 +898,33 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     return 0;
 }
 
-int lpx_revised_refactor(lpx_revised* r)
+// basis matrix B = [A | I][:, Bidx] into r->Mb (m x ldp, zero padded)
+static int rv_gather(lpx_revised* r, const RvParams& p, hipStream_t s)
 {
-    if (!r) { set_error("lpx_revised_refactor: null handle"); return LPX_EINVAL; }
     const int m = r->m;
-    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    if (!r->Mb) {
+        LPX_HIP_TRY(hipMalloc((void**)&r->Mb, sizeof(double) * (size_t)m * r->ldp));
+        LPX_HIP_TRY(hipMemsetAsync(r->Mb, 0, sizeof(double) * (size_t)m * r->ldp, s));
+    }
+    hipLaunchKernelGGL(rv_gather_basis, dim3((m + 255) / 256, m), dim3(256), 0, s, p, r->Mb, r->ldp);
+    LPX_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// exact refactorisation: the reference's Invert on the device, bit for bit (K7')
+static int rv_refactor_exact(lpx_revised* r, const RvParams& p)
+{
+    const int m = r->m;
     // W is rebuilt from the basis: a rank-1 update still pending on the old W is dropped, not applied
     if (r->fused) { hipLaunchKernelGGL(rv_clear_pending, dim3(1), dim3(1), 0, r->stream, r->st); LPX_HIP_TRY(hipStreamSynchronize(r->stream)); }
     if (!r->inv) {
         r->inv = new InvWork();
         int rc = inv_alloc(*r->inv, m);
         if (rc) { delete r->inv; r->inv = nullptr; return rc; }
-        LPX_HIP_TRY(hipMalloc((void**)&r->Mb, sizeof(double) * (size_t)m * m));
     }
-    lpx_run_opts od; lpx_default_opts(&od, 1);
-    RvParams p = rv_params(r, &od);
     InvWork& w = *r->inv;
-    hipLaunchKernelGGL(rv_gather_basis, dim3((m + 255) / 256, m), dim3(256), 0, w.stream, p, r->Mb, m);
-    hipLaunchKernelGGL(inv_build, dim3((w.ld + 255) / 256, m), dim3(256), 0, w.stream, (const double*)r->Mb, m, m, w.A, w.ld);
+    { int rc = rv_gather(r, p, w.stream); if (rc) return rc; }
+    hipLaunchKernelGGL(inv_build, dim3((w.ld + 255) / 256, m), dim3(256), 0, w.stream, (const double*)r->Mb, m, r->ldp, w.A, w.ld);
     LPX_HIP_TRY(hipGetLastError());
     int rc = inv_run(w);
     if (rc) return rc;
@@ -836,6 +932,115 @@ int lpx_revised_refactor(lpx_revised* r)
     hipLaunchKernelGGL(rv_refill_pi, dim3((m + 1 + 255) / 256), dim3(256), 0, w.stream, p, (const double*)r->c);
     LPX_HIP_TRY(hipGetLastError());
     LPX_HIP_TRY(hipStreamSynchronize(w.stream));
+    return 0;
+}
+
+// Fast refactorisation: Newton-Schulz steps X <- X + X (I - B X) on the FP64 matrix cores (lpx_mfma.hip), starting from the
+// maintained inverse.  Returns 1 when X is too far from B^-1 for the step to contract (the caller then runs the exact one).
+static int rv_refactor_fast(lpx_revised* r, const RvParams& p)
+{
+    const int m = r->m, ldp = r->ldp, ldw = r->ldw;
+    hipStream_t s = r->stream;
+    { int rc = rv_flush_pending(r); if (rc) return rc; }             // the starting X is W as the last pivot left it
+    if (!r->nsR) {
+        LPX_HIP_TRY(hipMalloc((void**)&r->nsR, sizeof(double) * (size_t)m * ldp));
+        LPX_HIP_TRY(hipMalloc((void**)&r->nsX, sizeof(double) * (size_t)m * ldw));
+        LPX_HIP_TRY(hipMalloc((void**)&r->nsmax, sizeof(unsigned long long)));
+        LPX_HIP_TRY(hipMalloc((void**)&r->scratch, sizeof(double) * (size_t)RVP_RS * ldw));
+    }
+    { int rc = rv_gather(r, p, s); if (rc) return rc; }
+    if (!r->ev0) { LPX_HIP_TRY(hipEventCreate(&r->ev0)); LPX_HIP_TRY(hipEventCreate(&r->ev1)); }
+    r->gemm_ms = 0.0; r->gemm_calls = 0;
+    auto timed = [&](float& acc_ms) -> int { LPX_HIP_TRY(hipEventSynchronize(r->ev1)); float ms = 0.f; LPX_HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1)); acc_ms += ms; return 0; };
+    float gms = 0.f;
+    for (int step = 0; step < 3; ++step) {
+        LPX_HIP_TRY(hipMemsetAsync(r->nsmax, 0, sizeof(unsigned long long), s));
+        LPX_HIP_TRY(hipEventRecord(r->ev0, s));
+        LPX_HIP_TRY(launch_dgemm_mfma(r->Mb, ldp, r->W, ldw, r->nsR, ldp, nullptr, 0, m, m, m, 0, r->nsmax, s));      // R = I - B X
+        LPX_HIP_TRY(hipEventRecord(r->ev1, s));
+        unsigned long long bits = 0;
+        LPX_HIP_TRY(hipMemcpyAsync(&bits, r->nsmax, sizeof(bits), hipMemcpyDeviceToHost, s));
+        LPX_HIP_TRY(hipStreamSynchronize(s));
+        double rmax; std::memcpy(&rmax, &bits, sizeof(rmax));
+        { int rc = timed(gms); if (rc) return rc; } r->gemm_calls++; r->gemm_ms = gms;
+        if (!(rmax * m < 0.1)) return 1;                             // not a contraction for sure: |R|_inf <= m * max|R_ij|
+        if (step > 0 && rmax * m < 1e-13) break;                     // already at working precision
+        LPX_HIP_TRY(hipEventRecord(r->ev0, s));
+        LPX_HIP_TRY(launch_dgemm_mfma(r->W, ldw, r->nsR, ldp, r->nsX, ldw, r->W, ldw, m, m, m, 1, nullptr, s));        // X' = X + X R
+        LPX_HIP_TRY(hipEventRecord(r->ev1, s));
+        { int rc = timed(gms); if (rc) return rc; } r->gemm_calls++; r->gemm_ms = gms;
+        LPX_HIP_TRY(hipMemcpy2DAsync(r->W, sizeof(double) * ldw, r->nsX, sizeof(double) * ldw, sizeof(double) * m, m, hipMemcpyDeviceToDevice, s));
+        r->fast_steps++;
+        if ((double)m * rmax * rmax * m < 1e-13) break;              // residual of X' is R^2: |R^2|_inf <= (m max|R_ij|)^2
+    }
+    hipLaunchKernelGGL(rv_refill_xb, dim3((m + 3) / 4), dim3(256), 0, s, p, (const double*)r->b);
+    hipLaunchKernelGGL(rv_refill_pi_partial, dim3((m + 1 + 63) / 64, RVP_RS), dim3(256), 0, s, p, (const double*)r->c, r->scratch);
+    hipLaunchKernelGGL(rv_refill_pi_final, dim3((m + 1 + 255) / 256), dim3(256), 0, s, p, (const double*)r->scratch);
+    LPX_HIP_TRY(hipGetLastError());
+    LPX_HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int lpx_revised_refactor(lpx_revised* r)
+{
+    if (!r) { set_error("lpx_revised_refactor: null handle"); return LPX_EINVAL; }
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    lpx_run_opts od; lpx_default_opts(&od, 1);
+    RvParams p = rv_params(r, &od);
+    r->refactors++;
+    if (r->refactor_mode == 1) {
+        const int rc = rv_refactor_fast(r, p);
+        if (rc <= 0) return rc;
+        r->fast_fallbacks++;                                         // X too far from B^-1: exact inversion instead
+    }
+    return rv_refactor_exact(r, p);
+}
+
+int lpx_revised_set_refactor_mode(lpx_revised* r, int mode)
+{
+    if (!r || mode < 0 || mode > 1) { set_error("lpx_revised_set_refactor_mode: mode is 0 (exact) or 1 (fast)"); return LPX_EINVAL; }
+    r->refactor_mode = mode;
+    return 0;
+}
+
+int lpx_revised_set_drift_policy(lpx_revised* r, int check_every, double tol)
+{
+    if (!r || check_every < 0 || !(tol >= 0.0)) { set_error("lpx_revised_set_drift_policy: bad argument"); return LPX_EINVAL; }
+    r->drift_every = check_every; r->drift_tol = tol;
+    return 0;
+}
+
+int lpx_revised_residual(lpx_revised* r, double* rel, double* abs_)
+{
+    if (!r) { set_error("lpx_revised_residual: null handle"); return LPX_EINVAL; }
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    { const int rc = rv_flush_pending(r); if (rc) return rc; }
+    const int m = r->m;
+    if (!r->resid) LPX_HIP_TRY(hipMalloc((void**)&r->resid, sizeof(double) * ((size_t)RVR_KS * m + 2)));
+    lpx_run_opts od; lpx_default_opts(&od, 1);
+    RvParams p = rv_params(r, &od);
+    hipLaunchKernelGGL(rv_resid_partial, dim3((m + 255) / 256, RVR_KS), dim3(256), 0, r->stream, p, r->resid + 2);
+    hipLaunchKernelGGL(rv_resid_final, dim3(1), dim3(1024), 0, r->stream, p, (const double*)(r->resid + 2), (const double*)r->b, r->resid);
+    LPX_HIP_TRY(hipGetLastError());
+    double out[2] = {0, 0};
+    LPX_HIP_TRY(hipMemcpyAsync(out, r->resid, sizeof(out), hipMemcpyDeviceToHost, r->stream));
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    r->last_residual = out[0];
+    if (rel) *rel = out[0];
+    if (abs_) *abs_ = out[1];
+    return 0;
+}
+
+int lpx_revised_refactor_stats(lpx_revised* r, int* refactors, int* fast_steps, int* fast_fallbacks, double* last_residual,
+                               double* gemm_ms, int* gemm_calls)
+{
+    if (!r) return LPX_EINVAL;
+    if (gemm_ms) *gemm_ms = r->gemm_ms;
+    if (gemm_calls) *gemm_calls = r->gemm_calls;
+    if (refactors) *refactors = r->refactors;
+    if (fast_steps) *fast_steps = r->fast_steps;
+    if (fast_fallbacks) *fast_fallbacks = r->fast_fallbacks;
+    if (last_residual) *last_residual = r->last_residual;
     return 0;
 }
 
@@ -852,17 +1057,20 @@ int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void
 {
     if (!r) { set_error("lpx_revised_run: null handle"); return LPX_EINVAL; }
     lpx_run_opts d; if (!o) { lpx_default_opts(&d, 1); o = &d; }
-    if (r->refactor_every <= 0) {
+    // Segments: `refactor_every` iterations followed by an unconditional refactorisation (k = 1 is the reference's own
+    // schedule, :128), or -- the default -- `drift_every` iterations followed by the residual check of the maintained
+    // inverse and a refactorisation only when it has drifted past `drift_tol`.
+    const int seg_len = r->refactor_every > 0 ? r->refactor_every : r->drift_every;
+    if (seg_len <= 0 || seg_len >= o->max_iter) {
         const int status = revised_run_segment(r, o, cb, user, st, 0);
         const int rc = rv_flush_pending(r);             // W as the last pivot left it, before anyone looks at it
         return rc ? rc : status;
     }
-    // segments of `refactor_every` iterations, B^-1 recomputed from the basis in between (K7')
     lpx_stats total; std::memset(&total, 0, sizeof(total));
     int done = 0, status = LPX_ITER_LIMIT;
     while (done < o->max_iter) {
         lpx_run_opts seg = *o;
-        seg.max_iter = std::min(o->max_iter, done + r->refactor_every);
+        seg.max_iter = std::min(o->max_iter, done + seg_len);
         lpx_stats s1; std::memset(&s1, 0, sizeof(s1));
         status = revised_run_segment(r, &seg, cb, user, &s1, done);
         total.launches += s1.launches; total.loop_ms += s1.loop_ms; total.update_ms_sum += s1.update_ms_sum;
@@ -870,8 +1078,17 @@ int lpx_revised_run(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_cb cb, void
         if (status != LPX_ITER_LIMIT) break;
         done = (int)s1.pivots;
         if (done >= o->max_iter) break;
-        int rc = lpx_revised_refactor(r);               // drops the pending update: W is rebuilt from the basis
-        if (rc) return rc;
+        const double t0 = now_ms();
+        if (r->refactor_every > 0) {
+            int rc = lpx_revised_refactor(r);           // exact mode drops the pending update: W is rebuilt from the basis
+            if (rc) return rc;
+        } else {
+            double rel = 0.0;
+            int rc = lpx_revised_residual(r, &rel, nullptr);
+            if (rc) return rc;
+            if (!(rel <= r->drift_tol)) { rc = lpx_revised_refactor(r); if (rc) return rc; }
+        }
+        total.loop_ms += now_ms() - t0;
     }
     if (st) { double h = st->h2d_ms, dd = st->d2h_ms; *st = total; st->h2d_ms = h; st->d2h_ms = dd; }
     { const int rc = rv_flush_pending(r); if (rc) return rc; }

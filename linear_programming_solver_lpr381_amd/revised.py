@@ -78,6 +78,26 @@ class DeviceRevised:
     def set_refactor(self, every: int):
         check(lib().lpx_revised_set_refactor(self._h, int(every)))
 
+    def set_refactor_mode(self, mode: int):
+        """0 = exact (the reference's Invert, bit for bit), 1 = fast (Newton-Schulz on the FP64 matrix cores)."""
+        check(lib().lpx_revised_set_refactor_mode(self._h, int(mode)))
+
+    def set_drift_policy(self, check_every: int, tol: float = 1e-9):
+        """Residual check of the maintained inverse every `check_every` iterations (0 = off); refactorise above `tol`."""
+        check(lib().lpx_revised_set_drift_policy(self._h, int(check_every), float(tol)))
+
+    def residual(self) -> Tuple[float, float]:
+        """(rho, max_i |(B x_B)_i - b_i|) with rho = that maximum / (1 + max |b_i|), evaluated on the device."""
+        rel, ab = C.c_double(), C.c_double()
+        check(lib().lpx_revised_residual(self._h, C.byref(rel), C.byref(ab)))
+        return rel.value, ab.value
+
+    def refactor_stats(self) -> dict:
+        a, b, c_, d, g, gc = C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
+        check(lib().lpx_revised_refactor_stats(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(g), C.byref(gc)))
+        return {"refactors": a.value, "fast_steps": b.value, "fast_fallbacks": c_.value, "last_residual": d.value,
+                "gemm_ms": g.value, "gemm_calls": gc.value}
+
 
 def invert(M: np.ndarray) -> np.ndarray:
     """lpx_invert: the reference's Invert (Models/RevisedPrimalSimplex.cs:402-456) on the GPU, bit for bit."""

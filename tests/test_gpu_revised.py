@@ -149,3 +149,81 @@ def test_refactor_segments_fire_each_pivot_callback_once(gpu, oracle):
     assert status == 0 and st["pivots"] == len(ref.trace) and tr.tolist() == ref.trace.tolist()
     assert [e[0] for e in ev] == list(range(1, len(tr) + 1))
     assert [[e[1], e[2]] for e in ev] == tr.tolist()
+
+
+@pytest.mark.parametrize("m,n,seed", [(1, 3, 1), (2, 5, 2), (12, 20, 3), (40, 64, 3), (100, 150, 4), (257, 300, 5)])
+def test_fast_refactor_newton_schulz_on_matrix_cores(gpu, oracle, m, n, seed):
+    """lpx_revised_set_refactor_mode(1): B^-1 refreshed by Newton-Schulz steps whose two m x m x m contractions run on
+    v_mfma_f64_16x16x4_f64 (csrc/lpx_mfma.hip), any m (ragged tiles).  Bar: |B^-1 B - I| <= 1e-12 here, the same inverse
+    as the exact Gauss-Jordan to 1e-10, x_B / z to 1e-9."""
+    c, A, b = synth.dense_lp(m, n, seed=seed)
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.run()
+        Bidx, _, xB0, z0 = rv.result()
+        rv.set_refactor_mode(1)
+        rv.refactor()
+        _, _, xB1, z1 = rv.result()
+        Binv1 = rv.binv()
+        st = rv.refactor_stats()
+        rv.set_refactor_mode(0)
+        rv.refactor()
+        Binv0 = rv.binv()
+        _, _, xB2, z2 = rv.result()
+    assert st["refactors"] == 1 and st["fast_steps"] >= 1 and st["fast_fallbacks"] == 0
+    full = np.hstack([A, np.eye(m)])
+    E = Binv1 @ full[:, Bidx] - np.eye(m)
+    assert np.abs(E).max() <= 1e-12, np.abs(E).max()
+    assert np.allclose(Binv1, Binv0, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(Binv0).max()))
+    assert np.allclose(xB1, xB2, rtol=1e-9, atol=1e-9) and abs(z1 - z2) <= 1e-9 * max(1.0, abs(z2))
+    assert np.allclose(xB1, xB0, rtol=1e-9, atol=1e-9) and abs(z1 - z0) <= 1e-9 * max(1.0, abs(z0))
+
+
+@pytest.mark.parametrize("every", [1, 4])
+def test_fast_refactor_keeps_the_oracle_pivots(gpu, oracle, every):
+    """Periodic refactorisation in fast mode: the pivot sequence, Bidx and Nidx order stay those of the oracle."""
+    m, n, seed = 40, 64, 3
+    c, A, b = synth.dense_lp(m, n, seed=seed)
+    ref = oracle.revised_solve(oracle.Problem(oracle.MAX, c, A, np.zeros(m, np.int32), b))
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.set_refactor_mode(1)
+        rv.set_refactor(every)
+        status, st = rv.run()
+        Bidx, Nidx, xB, z = rv.result()
+        tr = rv.trace()
+        stats = rv.refactor_stats()
+    assert status == 0 and tr.tolist() == ref.trace.tolist()
+    assert Bidx.tolist() == ref.Bidx.tolist() and Nidx.tolist() == ref.Nidx.tolist()
+    assert abs(z - ref.z_internal) <= REL * abs(ref.z_internal)
+    assert stats["refactors"] >= len(tr) // every - 1 and stats["fast_fallbacks"] == 0
+
+
+def test_drift_policy_checks_the_residual_and_refactors_only_when_asked(gpu, oracle):
+    """Default drift control (include/lpx.h): every `check_every` iterations the residual rho of the maintained inverse is
+    evaluated on the device; a refactorisation happens only above `tol`.  m = 1024: with the default tolerance nothing is
+    refactored and rho stays tiny; with tol = 0 every check refactors (fast mode) and the first 10 pivots are still the
+    oracle's (it re-inverts every iteration, Models/RevisedPrimalSimplex.cs:128)."""
+    m, n = 1024, 2048
+    c, A, b = synth.dense_lp(m, n)
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.set_drift_policy(100, 1e-9)
+        status, st = rv.run(max_iter=450)
+        s0 = rv.refactor_stats()
+        rho, absr = rv.residual()
+        Bidx, _, xB, z = rv.result()
+        tr0 = rv.trace()
+    assert status == 3 and st["pivots"] == 450
+    assert s0["refactors"] == 0 and 0.0 <= s0["last_residual"] <= 1e-10 and rho <= 1e-10
+    full_x = np.zeros(n + m); full_x[Bidx] = xB
+    assert np.abs(np.hstack([A, np.eye(m)]) @ full_x - b).max() <= 1e-9 * (1 + np.abs(b).max())
+    ref = oracle.revised_solve(oracle.Problem(oracle.MAX, c, A, np.zeros(m, np.int32), b), max_iter=10)
+    with gpu.DeviceRevised(A, -c, b) as rv:
+        rv.set_refactor_mode(1)
+        rv.set_drift_policy(3, 0.0)                      # every check refactors
+        status, st = rv.run(max_iter=10)
+        s1 = rv.refactor_stats()
+        tr = rv.trace()
+        Bidx1, Nidx1, _, z1 = rv.result()
+    assert s1["refactors"] == 3 and s1["fast_fallbacks"] == 0
+    assert tr.tolist() == ref.trace.tolist() == tr0[:10].tolist()
+    assert Bidx1.tolist() == ref.Bidx.tolist() and Nidx1.tolist() == ref.Nidx.tolist()
+    assert abs(z1 - ref.z_internal) <= REL * abs(ref.z_internal)

@@ -12,5 +12,11 @@ rv = L.DeviceRevised(A, -c, b); rv.run(max_iter=20, batch=20); rv.close()
 rv = L.DeviceRevised(A, -c, b)
 st, s = rv.run(max_iter=iters, batch=50)
 print(f"m={m} n={n}: status={st} iterations={s['pivots']} loop_ms={s['loop_ms']:.2f} us/iter={1e3*s['loop_ms']/max(s['pivots'],1):.2f}", flush=True)
-t0 = time.perf_counter(); rv.refactor(); print(f"refactor {time.perf_counter()-t0:.3f} s")
+print("residual", rv.residual())
+rv.set_refactor_mode(1)
+t0 = time.perf_counter(); rv.refactor(); print(f"fast refactor (first: allocations) {time.perf_counter()-t0:.4f} s", rv.refactor_stats(), rv.residual())
+st, s = rv.run(max_iter=iters, batch=50)
+t0 = time.perf_counter(); rv.refactor(); print(f"fast refactor {time.perf_counter()-t0:.4f} s", rv.refactor_stats(), rv.residual())
+rv.set_refactor_mode(0)
+t0 = time.perf_counter(); rv.refactor(); print(f"exact refactor {time.perf_counter()-t0:.3f} s", rv.residual())
 rv.close()
