@@ -104,9 +104,11 @@ def main():
     ap.add_argument("--roofline-pivots", type=int, default=400)
     ap.add_argument("--headline-pivots", type=int, default=200)
     ap.add_argument("--cpu-sample-pivots", type=int, default=240)
-    ap.add_argument("--bnb-nodes", type=int, default=400, help="node budget per rank (config 4 leg)")
+    ap.add_argument("--bnb-nodes", type=int, default=1600, help="GLOBAL node budget of the config 4 leg (strong scaling)")
+    ap.add_argument("--bnb-prune-n", type=int, default=60)
+    ap.add_argument("--bnb-prune-m", type=int, default=12)
     ap.add_argument("--bnb-concurrent", type=int, default=64)
-    ap.add_argument("--bnb-warm-nodes", type=int, default=4000, help="node budget per rank (warm-start leg)")
+    ap.add_argument("--bnb-warm-nodes", type=int, default=8000, help="GLOBAL node budget of the warm-start leg")
     ap.add_argument("--bnb-warm-concurrent", type=int, default=64)
     ap.add_argument("--knap-nodes", type=int, default=200000, help="pop budget per rank (config 5 leg)")
     ap.add_argument("--revised-iters", type=int, default=300)
@@ -222,42 +224,59 @@ def main():
 
     if not args.no_extras:
         progress(f"value leg done ({dt_s:.1f} s); B&B leg (config 4)")
-        # ---- config 4: sharded branch and bound (all ranks) -------------------------------------------
+        # ---- config 4: sharded branch and bound (all ranks), STRONG scaling: one global node budget ---------
+        def gather_counts(v):
+            """per-rank values (list over ranks), via all_gather"""
+            if world == 1:
+                return [float(v)]
+            t = torch.tensor([float(v)], dtype=torch.float64, device=coll_dev)
+            outl = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(outl, t)
+            return [float(x.item()) for x in outl]
+
+        def bnb_leg(problem, label, **kw):
+            solver = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw)
+            barrier()
+            t1 = time.perf_counter()
+            rb = solver.Solve(problem)
+            barrier()
+            tb = time.perf_counter() - t1
+            lp_total, tb_max = reduce_sum_max(rb.LpSolves, tb)
+            piv_total, _ = reduce_sum_max(rb.Stats["pivots"], tb)
+            per_rank = gather_counts(rb.LpSolves)
+            aux = list(rb.Aux) if rb.Aux else [0, 0, 0, 0]
+            return {"workload": label, "nodes_per_s": lp_total / tb_max, "lp_relaxations": lp_total, "pivots": piv_total,
+                    "pivots_per_node": piv_total / max(lp_total, 1), "wall_s": tb_max,
+                    "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
+                    "scaling": "strong (one global node budget, split over the ranks at the hand-out)",
+                    "per_rank_lp_relaxations": per_rank,
+                    "imbalance_max_over_mean": max(per_rank) / max(sum(per_rank) / len(per_rank), 1e-9),
+                    "levels": aux[0], "allreduces": aux[1], "rebalancing_rounds": aux[2], "node_descriptors_moved": aux[3],
+                    "collective": f"1 all-reduce(max) of {{incumbent, have_work, failed, max depth, pool size per rank}} per level "
+                                  f"(+1 when descriptors move), {backend_name}" if world > 1 else "none (1 rank)",
+                    "multi_gpu_status": "unmeasured on hardware (no multi-GPU box reachable from the build sessions)"}
+
         cb, Ab, relb, bb = synth.binary_ip(512, 256)
         pb = L.LPProblem.from_arrays(0, cb, Ab, relb, bb)
-        bnb = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=args.bnb_concurrent,
-                               max_nodes=args.bnb_nodes, rank=rank, world=world, allreduce_max=allreduce_max)
-        barrier()
-        t1 = time.perf_counter()
-        rb = bnb.Solve(pb)
-        barrier()
-        tb = time.perf_counter() - t1
-        lp_total, tb_max = reduce_sum_max(rb.LpSolves, tb)
-        piv_total, _ = reduce_sum_max(rb.Stats["pivots"], tb)
-        out["bnb"] = {"workload": "random 0/1 IP n=512 m=256 + 512 rows x_j<=1 (config 4), repaired mode, "
-                                  "level-synchronous sharded node queue, node budget per rank "
-                                  f"{args.bnb_nodes}, {args.bnb_concurrent} node LPs in flight per GPU",
-                      "nodes_per_s": lp_total / tb_max, "lp_relaxations": lp_total, "pivots": piv_total,
-                      "wall_s": tb_max, "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
-                      "collective": f"1 all-reduce(max) of {{incumbent, have_work}} per level ({backend_name})"
-                                    if world > 1 else "none (1 rank)",
-                      "multi_gpu_status": "unmeasured on hardware (no 8-GPU run yet)"}
+        out["bnb"] = bnb_leg(pb, "random 0/1 IP n=512 m=256 + 512 rows x_j<=1 (config 4), repaired mode, level-synchronous "
+                                 f"sharded node queue, every node re-solved from the slack basis as the reference does; GLOBAL budget "
+                                 f"{args.bnb_nodes} nodes, {args.bnb_concurrent} node LPs in flight per GPU",
+                             bnb_search=1, concurrent_nodes=args.bnb_concurrent, max_nodes=args.bnb_nodes)
+        out["bnb"]["incumbent_note"] = ("no integer node exists within the reference's recursion cap: the LP relaxation has up to 256 "
+                                        "fractional basic variables, one is fixed per level and SolveNode stops at depth 200 "
+                                        "(Models/Branch&Bound.cs:25,132) -- a depth-first-K dive of 4000 nodes ends in 'maximum depth' "
+                                        "leaves (tools/probe_bnb.py); the shared bound is exercised by `bnb_prune` below")
         # ---- config 4 again with warm-started children (SURVEY 8f rank 3; NOT the reference's re-solve) ------
-        bnbw = L.BranchAndBound(bnb_mode=1, bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent,
-                                max_nodes=args.bnb_warm_nodes, rank=rank, world=world, allreduce_max=allreduce_max)
-        barrier()
-        t1 = time.perf_counter()
-        rw = bnbw.Solve(pb)
-        barrier()
-        tw = time.perf_counter() - t1
-        lpw_total, tw_max = reduce_sum_max(rw.LpSolves, tw)
-        pivw_total, _ = reduce_sum_max(rw.Stats["pivots"], tw)
-        out["bnb_warm"] = {"workload": "config 4, same sharded level search, children warm-started from the parent's final "
-                                       "tableau (dual loop only) -- an engine mode, not the reference's algorithm; node budget "
-                                       f"per rank {args.bnb_warm_nodes}, {args.bnb_warm_concurrent} node LPs per batch",
-                           "nodes_per_s": lpw_total / tw_max, "lp_relaxations": lpw_total, "pivots": pivw_total,
-                           "pivots_per_node": pivw_total / max(lpw_total, 1), "wall_s": tw_max,
-                           "incumbent": rw.OptimalValue if rw.OptimalValue > -1e300 else None}
+        out["bnb_warm"] = bnb_leg(pb, "config 4, same sharded level search, children warm-started from the parent's final tableau (dual "
+                                      f"loop only) -- an engine mode, not the reference's algorithm; GLOBAL budget {args.bnb_warm_nodes} nodes, "
+                                      f"{args.bnb_warm_concurrent} node LPs per batch",
+                                  bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent, max_nodes=args.bnb_warm_nodes)
+        # ---- a 0/1 IP small enough to be SOLVED: incumbents appear, the all-reduced bound prunes, pools are rebalanced ----
+        cs, As, rels, bs = synth.binary_ip(args.bnb_prune_n, args.bnb_prune_m)
+        ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)
+        out["bnb_prune"] = bnb_leg(ps, f"random 0/1 IP n={args.bnb_prune_n} m={args.bnb_prune_m} (+{args.bnb_prune_n} bound rows), repaired mode, "
+                                       "sharded level search with the depth-first-K pool, solved to optimality (no node budget)",
+                                   bnb_search=1, bnb_dive=1, concurrent_nodes=32, max_nodes=0)
         progress("knapsack leg (config 5)")
         # ---- config 5: sharded knapsack (all ranks) ---------------------------------------------------
         pk, wk, capk = synth.knapsack(100_000)

@@ -280,25 +280,13 @@ typedef struct lpx_solve_opts {
                               slack basis, as the reference), 2 = the same with warm-started children */
     int concurrent_nodes;  /* node LPs in flight per GPU (level search) */
     int rank, world;       /* shard of this process (level search / knapsack rounds) */
-    int64_t max_nodes;     /* 0 = unlimited */
+    int64_t max_nodes;     /* 0 = unlimited; sharded searches: node budget of the WHOLE job, split over the ranks */
     /* incumbent exchange, MAX over ranks in place (RCCL all-reduce in production); NULL = 1 process */
     void (*allreduce_max)(void* user, double* vals, int count);
     void* allreduce_user;
     /* Action<string,bool[,]>: text + optional R x C highlight mask (NULL = none) */
     void (*text_cb)(void* user, const char* text, const uint8_t* highlight, int R, int C);
     void* text_user;
-    /* TEST SEAMS -- NULL in every product path.  They let the CPU-only test-suite drive the sharded
-     * host logic (frontier partition, per-level all-reduce, termination) under torch.distributed/gloo
-     * with world_size 2 on a box without a GPU, by standing in for the device loops:
-     *   test_node_lp      replaces lpx_multi_run + lpx_tableau_solution for ONE prepared node tableau
-     *                     (T is R x C row-major, modified in place; returns the LPX_* status)
-     *   test_knap_relax   replaces lpx_knapsack_relax_batch (same argument meaning) */
-    int (*test_node_lp)(void* user, double* T, int R, int C, int32_t* basis, int dual, int repaired,
-                        int max_iter, int nvars, double* x, double* z, int64_t* pivots);
-    int (*test_knap_relax)(void* user, int count, const int32_t* off, const int32_t* fix_idx,
-                           const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
-                           double* frac_val);
-    void* test_user;
     int bnb_dive;          /* sharded searches: 0 = whole frontier per round (breadth first), 1 = only the deepest
                               `concurrent_nodes` nodes of the pool per round (depth-first-K: reaches incumbents early) */
 } lpx_solve_opts;
@@ -315,7 +303,8 @@ typedef struct lpx_result {                        /* SimplexResult, Models/Prim
     int64_t lp_solves, nodes;       /* branch and bound */
     int n_log; int32_t* node_log;   /* [3*n_log]: depth, outcome, branching variable */
     double* node_z;                 /* [n_log] */
-    double aux[4];                  /* revised: {z_original, z_internal}; knapsack: {relaxations, popped, expanded, max_heap} */
+    double aux[4];                  /* revised: {z_original, z_internal}; knapsack: {relaxations, popped, expanded, max_heap};
+                                       sharded B&B: {levels, all-reduces, rebalancing rounds, node descriptors moved} */
     lpx_stats stats;
     int n_cuts; double* cuts;       /* cutting plane: [n_cuts*(nvars+1)] = (A[0..nvars), B) per cut, in the order added */
 } lpx_result;

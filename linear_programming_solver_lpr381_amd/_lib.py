@@ -46,7 +46,7 @@ ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int)
 
 
-# test seams (include/lpx.h): only the CPU test-suite sets these
+# test seams (include/lpx_test.h): only the CPU test-suite sets these
 TEST_NODE_LP = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp,
                            C.POINTER(C.c_int64))
 TEST_KNAP_RELAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp)
@@ -62,8 +62,12 @@ class SolveOpts(C.Structure):
                 ("concurrent_nodes", C.c_int), ("rank", C.c_int), ("world", C.c_int),
                 ("max_nodes", C.c_int64), ("allreduce_max", ALLREDUCE_CB), ("allreduce_user", C.c_void_p),
                 ("text_cb", TEXT_CB), ("text_user", C.c_void_p),
-                ("test_node_lp", TEST_NODE_LP), ("test_knap_relax", TEST_KNAP_RELAX), ("test_user", C.c_void_p),
                 ("bnb_dive", C.c_int)]
+
+
+class TestSeams(C.Structure):
+    """include/lpx_test.h: test-only stand-ins for the device loops (never installed by the package itself)."""
+    _fields_ = [("node_lp", TEST_NODE_LP), ("knap_relax", TEST_KNAP_RELAX), ("user", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -167,6 +171,8 @@ def lib() -> C.CDLL:
     L.lpx_knapsack_order.argtypes = [vp, ip]
     L.lpx_knapsack_relax_batch.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
     L.lpx_knapsack_relax_batch2.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
+    L.lpx_test_set_seams.argtypes = [C.POINTER(TestSeams)]
+    L.lpx_test_set_seams.restype = None
     L.lpx_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
     L.lpx_default_solve_opts.restype = None
     L.lpx_solve.argtypes = [C.POINTER(Problem), C.c_char_p, C.POINTER(SolveOpts), C.POINTER(Result)]

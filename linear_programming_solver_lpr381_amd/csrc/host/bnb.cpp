@@ -107,6 +107,16 @@ struct Ctx {
     double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
     SimplexResult* out; HandlePool pool; bool stop = false;
     bool count_work = true;      // false while this rank only mirrors the replicated warm-up of rank 0
+    // Node budget of the sharded searches.  It is evaluated IDENTICALLY on every rank while the warm-up is replicated
+    // (budget_used counts every rank's copy of the same nodes), so all ranks leave that phase together; at the hand-out
+    // what is left of the GLOBAL budget (opt.max_nodes) is split evenly and each rank then counts its own nodes.
+    int64_t budget_used = 0, budget_cap = 0;
+    bool over_budget() const { return budget_cap > 0 && budget_used >= budget_cap; }
+    // DFS-order key of the incumbent's node: one bit per branching level, 0 = the ceil child the reference visits first
+    // (Models/Branch&Bound.cs:256), 1 = the floor child.  Lexicographically smaller == earlier in the reference's DFS.
+    std::vector<uint8_t> best_key; bool tie_by_key = false;
+    // statistics of the sharded search (SimplexResult::Aux)
+    int64_t levels = 0, allreduces = 0, rebalances = 0, moved = 0;
     std::vector<lpx_tableau*> released;
     std::map<std::pair<int, int>, lpx_store*> stores;
     lpx_store* store_for(lpx_tableau* h) {
@@ -344,11 +354,19 @@ void node_log(Ctx& c, int depth, int outcome, int var, double z)
     c.out->NodeZ.push_back(z);
 }
 
-void set_incumbent(Ctx& c, const std::vector<double>& x, double z)
+std::vector<uint8_t> key_of(const std::vector<Cut>& cuts)
+{
+    std::vector<uint8_t> k(cuts.size());
+    for (size_t i = 0; i < cuts.size(); ++i) k[i] = cuts[i].rel == Rel::GE ? 0 : 1;
+    return k;
+}
+
+void set_incumbent(Ctx& c, const std::vector<double>& x, double z, const std::vector<Cut>& cuts = {})
 {
     c.best = z; c.has_best = true;
     c.best_x.resize(x.size());
     for (size_t i = 0; i < x.size(); ++i) c.best_x[i] = std::nearbyint(x[i]);    // RoundInt, :296
+    c.best_key = key_of(cuts);
 }
 
 // The decision part of SolveNode (:156-230) for a solved relaxation.  Returns the branching
@@ -365,9 +383,20 @@ int decide(Ctx& c, const std::vector<Cut>& cuts, const NodeLP& lp, int depth, co
     if (c.cb) c.log(name + " LP solution: z* = " + FormatF(z, 3));
     if (!IsFeasible(x, *c.root, cuts)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
     const double bestObj = c.has_best ? c.best : -INFINITY;
+    // Sharded searches visit nodes level by level, not in the reference's depth-first order.  Among integer nodes with
+    // EXACTLY the incumbent's z the one the reference's DFS reaches first keeps the solution vector (first found wins
+    // there, :182-195): smaller DFS-order key.  Counters and the node log are untouched (the node is pruned as always).
+    if (c.tie_by_key && c.has_best && z == c.best && IsIntegral(x)) {
+        const std::vector<uint8_t> k = key_of(cuts);
+        if (c.best_x.empty() || k < c.best_key) {
+            c.best_x.resize(x.size());
+            for (size_t i = 0; i < x.size(); ++i) c.best_x[i] = std::nearbyint(x[i]);
+            c.best_key = k;
+        }
+    }
     if (z <= bestObj + EPS) { c.log(name + ": Pruned by bound (z* <= current best " + FormatF(bestObj, 3) + ")."); node_log(c, depth, O_PRUNED, -1, z); return -1; }   // :182-186
     if (IsIntegral(x)) {                                                     // :189-195
-        set_incumbent(c, x, z);
+        set_incumbent(c, x, z, cuts);
         c.log(name + " is integer feasible. Updated BestObjective = " + FormatF(z, 3));
         node_log(c, depth, O_INCUMBENT, -1, z); return -1;
     }
@@ -412,15 +441,60 @@ void SolveNode(Ctx& c, std::vector<Cut>& cuts, int depth, const std::string& nam
 // ---- search 1: level-synchronous frontier -----------------------------------------------------------
 struct FNode { std::vector<Cut> cuts; int depth; };
 
+// Everything the ranks tell each other goes through the ONE collective the boundary knows, all-reduce(MAX) in place
+// (RCCL in production): a value only rank r knows travels in slot r of a vector the other ranks fill with -inf.
+struct Exchange {
+    Ctx& c; int world, rank;
+    void max(double* v, int n) { c.opt.allreduce_max(v, n); c.allreduces++; }
+};
+
+// final ownership of the solution vector: among the ranks holding an x for the global best z, the one whose node comes
+// first in the reference's DFS order (smallest key) publishes it -- ONE all-reduce for the keys, one for x
+void publish_best(Ctx& c, Exchange& ex, int nvars)
+{
+    constexpr int CH = 5, BITS = 48;                                   // 240 key bits >= MaxDepth + 1 levels
+    const int world = ex.world, rank = ex.rank;
+    std::vector<double> keys((size_t)world * (CH + 1), -INFINITY);
+    const bool cand = c.has_best && !c.best_x.empty();
+    if (cand) {
+        keys[(size_t)rank * (CH + 1)] = 1.0;                           // "rank holds an x for the best z"
+        for (int k = 0; k < CH; ++k) {
+            double v = 0.0;
+            for (int b = 0; b < BITS; ++b) { const size_t i = (size_t)k * BITS + b; v = v * 2.0 + (i < c.best_key.size() ? c.best_key[i] : 1); }
+            keys[(size_t)rank * (CH + 1) + 1 + k] = v;
+        }
+    }
+    ex.max(keys.data(), (int)keys.size());
+    int owner = -1;
+    for (int r = 0; r < world; ++r) {
+        if (keys[(size_t)r * (CH + 1)] != 1.0) continue;
+        if (owner < 0) { owner = r; continue; }
+        for (int k = 1; k <= CH; ++k) {
+            const double a = keys[(size_t)r * (CH + 1) + k], b = keys[(size_t)owner * (CH + 1) + k];
+            if (a != b) { if (a < b) owner = r; break; }
+        }
+    }
+    if (owner < 0) return;
+    std::vector<double> xs(nvars, -INFINITY);
+    if (owner == rank) xs = c.best_x;
+    ex.max(xs.data(), nvars);
+    c.best_x = xs;
+}
+
 void LevelSearch(Ctx& c)
 {
     const int world = std::max(1, c.opt.world), rank = c.opt.rank;
+    const bool sharded = world > 1 && (bool)c.opt.allreduce_max;
+    Exchange ex{c, world, rank};
+    c.tie_by_key = true;
     // The replicated warm-up only has to seed every rank with a subtree: 2 nodes per rank.  Its solves are
     // redundant across ranks, so only rank 0 counts them (LpSolves / Nodes stay whole-job totals when summed).
     const size_t want = (size_t)world * 2;
     std::vector<FNode> frontier{FNode{{}, 0}};
     bool replicated = world > 1;
     c.count_work = !(replicated && rank != 0);
+    c.budget_used = 0; c.budget_cap = c.opt.max_nodes;
+    bool failed = false; std::string fail_msg; int fail_code = 0;
     for (;;) {
         if (replicated && frontier.size() >= want) {
             // hand the replicated frontier out: node i -> rank i % world, subtrees stay local from here on
@@ -429,6 +503,10 @@ void LevelSearch(Ctx& c)
             frontier.swap(mine);
             replicated = false;
             c.count_work = true;
+            if (c.opt.max_nodes > 0) {                                 // the rest of the global budget, split evenly
+                const int64_t left = std::max<int64_t>(0, c.opt.max_nodes - c.budget_used);
+                c.budget_cap = c.budget_used + (left + world - 1) / world;
+            }
         }
         // this round's nodes: the whole frontier (breadth first) or, with bnb_dive, its deepest K nodes
         std::vector<FNode> parked;
@@ -443,13 +521,21 @@ void LevelSearch(Ctx& c)
         std::vector<NodeLP*> group;
         std::vector<char> skip(frontier.size(), 0);
         for (size_t i = 0; i < frontier.size(); ++i) {
-            if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
+            if (failed || c.over_budget()) { skip[i] = 1; c.stop = true; continue; }
+            c.budget_used++;
             if (c.count_work) c.out->Nodes++;
             if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
             if (c.opt.test_node_lp) prepare(c, make_node(*c.root, frontier[i].cuts), lps[i]); else prepare_device(c, frontier[i].cuts, lps[i]);
             group.push_back(&lps[i]);
         }
-        solve_group(c, group, c.root->NumVars());
+        c.levels++;
+        try { solve_group(c, group, c.root->NumVars()); }
+        catch (const LpxException& e) {
+            // a rank that leaves the loop would leave its peers waiting in the level's all-reduce: keep taking part, tell them
+            if (!sharded || replicated) throw;
+            failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true;
+            for (size_t i = 0; i < frontier.size(); ++i) if (!skip[i]) skip[i] = 1;
+        }
         std::vector<FNode> next;
         for (size_t i = 0; i < frontier.size(); ++i) {
             if (skip[i] == 1) continue;
@@ -464,24 +550,80 @@ void LevelSearch(Ctx& c)
         }
         frontier.swap(next);
         for (FNode& f : parked) frontier.push_back(std::move(f));
-        // one all-reduce(max) per level: incumbent bound and "someone still has work"
-        double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
-        if (!replicated && world > 1 && c.opt.allreduce_max) {
-            const double mine = vals[0];
-            c.opt.allreduce_max(vals, 2);
-            if (vals[0] > mine + 0.0) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); } }
+        if (c.stop) frontier.clear();
+        if (!sharded || replicated) {
+            if (frontier.empty() || c.stop) break;
+            continue;
         }
+        // ---- X1: ONE all-reduce(max) per level: incumbent bound, "someone still has work", "someone failed", the deepest
+        //      pooled node, and every rank's pool size (slot r; -1 = this rank takes no more nodes) for the rebalancing below
+        std::vector<double> vals(4 + (size_t)world, -INFINITY);
+        int maxd = 0; for (const FNode& f : frontier) maxd = std::max(maxd, f.depth);
+        vals[0] = c.has_best ? c.best : -INFINITY;
+        vals[1] = frontier.empty() ? 0.0 : 1.0;
+        vals[2] = failed ? 1.0 : 0.0;
+        vals[3] = (double)maxd;
+        vals[4 + rank] = c.stop ? -1.0 : (double)frontier.size();
+        const double mine = vals[0];
+        ex.max(vals.data(), (int)vals.size());
+        if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
+        if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
         if (vals[1] == 0.0) break;
+        // ---- rebalancing: node descriptors (branching rows) move, tableaux never do -- a node is rebuilt from the root model
+        //      wherever it is solved, exactly as the reference re-solves every node from scratch (Models/Branch&Bound.cs:148,233-248)
+        std::vector<int64_t> size(world);
+        int64_t total = 0, smax = 0, smin = INT64_MAX; int active = 0;
+        for (int r = 0; r < world; ++r) { size[r] = (int64_t)vals[4 + r]; if (size[r] >= 0) { total += size[r]; smax = std::max(smax, size[r]); smin = std::min(smin, size[r]); ++active; } }
+        const int64_t slack = std::max<int64_t>(2, c.opt.concurrent_nodes);
+        if (active >= 2 && ((smin == 0 && smax >= 2) || smax - smin > 2 * slack)) {
+            std::vector<int64_t> fin(world, -1);
+            { int64_t base = total / active, rem = total % active; int a = 0;
+              for (int r = 0; r < world; ++r) if (size[r] >= 0) { fin[r] = base + (a < rem ? 1 : 0); ++a; } }
+            struct Move { int from, to; int64_t count; };
+            std::vector<Move> moves;
+            { int d = 0, t = 0; std::vector<int64_t> give(world, 0), take(world, 0);
+              for (int r = 0; r < world; ++r) if (size[r] >= 0) { give[r] = std::max<int64_t>(0, size[r] - fin[r]); take[r] = std::max<int64_t>(0, fin[r] - size[r]); }
+              while (d < world && t < world) {
+                  if (give[d] == 0) { ++d; continue; }
+                  if (take[t] == 0) { ++t; continue; }
+                  const int64_t k = std::min(give[d], take[t]);
+                  moves.push_back({d, t, k}); give[d] -= k; take[t] -= k;
+              } }
+            int64_t nmoved = 0; for (const Move& mv : moves) nmoved += mv.count;
+            if (nmoved > 0) {
+                const int D = (int)vals[3];
+                const size_t stride = 1 + 3 * (size_t)std::max(D, 1);
+                std::vector<double> buf((size_t)nmoved * stride, -INFINITY);
+                size_t slot = 0;
+                for (const Move& mv : moves) {
+                    if (mv.from == rank)
+                        for (int64_t k = 0; k < mv.count; ++k) {                 // donors give from the end of their pool
+                            const FNode f = std::move(frontier.back()); frontier.pop_back();
+                            double* b = &buf[(slot + (size_t)k) * stride];
+                            b[0] = (double)f.cuts.size();
+                            for (size_t e = 0; e < f.cuts.size(); ++e) { b[1 + 3 * e] = f.cuts[e].var; b[2 + 3 * e] = (double)(int)f.cuts[e].rel; b[3 + 3 * e] = f.cuts[e].bound; }
+                        }
+                    slot += (size_t)mv.count;
+                }
+                ex.max(buf.data(), (int)buf.size());
+                slot = 0;
+                for (const Move& mv : moves) {
+                    if (mv.to == rank)
+                        for (int64_t k = 0; k < mv.count; ++k) {
+                            const double* b = &buf[(slot + (size_t)k) * stride];
+                            FNode f; const int nc = (int)b[0]; f.depth = nc;
+                            for (int e = 0; e < nc; ++e) f.cuts.push_back({(int)b[1 + 3 * e], (Rel)(int)b[2 + 3 * e], b[3 + 3 * e]});
+                            frontier.push_back(std::move(f));
+                        }
+                    slot += (size_t)mv.count;
+                }
+                c.rebalances++; c.moved += nmoved;
+            }
+        }
     }
-    if (world > 1 && c.opt.allreduce_max) {
-        // final ownership: lowest rank holding x for the global best publishes it (MAX of -rank, then MAX of x)
-        double own = (c.has_best && !c.best_x.empty()) ? -(double)rank : -INFINITY;
-        c.opt.allreduce_max(&own, 1);
-        const int n = c.root->NumVars();
-        std::vector<double> xs(n, -INFINITY);
-        if (own == -(double)rank && c.has_best && !c.best_x.empty()) xs = c.best_x;
-        if (own != -INFINITY) { c.opt.allreduce_max(xs.data(), n); c.best_x = xs; }
-    }
+    if (sharded && !replicated && !failed) publish_best(c, ex, c.root->NumVars());
+    c.out->Aux = {(double)c.levels, (double)c.allreduces, (double)c.rebalances, (double)c.moved};
+    if (failed) throw LpxException(fail_code ? fail_code : LPX_EDEVICE, fail_msg);
 }
 
 // ---- search 2: level-synchronous frontier with WARM-STARTED children ----------------------
@@ -498,6 +640,8 @@ void WarmSearch(Ctx& c)
     const size_t want = (size_t)world * 2;
     bool replicated = world > 1;
     c.count_work = !(replicated && rank != 0);
+    c.budget_used = 0; c.budget_cap = c.opt.max_nodes; c.tie_by_key = true;
+    Exchange ex{c, world, rank};
     const bool root_dual = has_ge_or_eq(*c.root);
     if (!ensure_template(c, root_dual)) return;
     const int w = root_dual ? 1 : 0;
@@ -518,6 +662,7 @@ void WarmSearch(Ctx& c)
     std::vector<WNode> frontier;
     {   // root: cold solve, result parked
         NodeLP lp; prepare_device(c, std::vector<Cut>{}, lp); lp.keep = true;
+        c.budget_used++;
         if (c.count_work) c.out->Nodes++;
         std::vector<NodeLP*> g{&lp};
         solve_group(c, g, nvars);
@@ -537,6 +682,10 @@ void WarmSearch(Ctx& c)
             frontier.swap(mine);
             replicated = false;
             c.count_work = true;
+            if (c.opt.max_nodes > 0) {                                 // the rest of the global budget, split evenly
+                const int64_t left = std::max<int64_t>(0, c.opt.max_nodes - c.budget_used);
+                c.budget_cap = c.budget_used + (left + world - 1) / world;
+            }
         }
         std::vector<WNode> parked;
         if (c.opt.bnb_dive && !replicated && frontier.size() > (size_t)std::max(1, c.opt.concurrent_nodes)) {
@@ -549,7 +698,8 @@ void WarmSearch(Ctx& c)
         std::vector<NodeLP*> group;
         std::vector<char> skip(frontier.size(), 0);
         for (size_t i = 0; i < frontier.size(); ++i) {
-            if (c.opt.max_nodes > 0 && c.out->Nodes >= c.opt.max_nodes) { skip[i] = 1; c.stop = true; continue; }
+            if (c.over_budget()) { skip[i] = 1; c.stop = true; continue; }
+            c.budget_used++;
             if (c.count_work) c.out->Nodes++;
             if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
             NodeLP& lp = lps[i];
@@ -575,21 +725,17 @@ void WarmSearch(Ctx& c)
         }
         frontier.swap(next);
         for (WNode& f : parked) frontier.push_back(std::move(f));
+        c.levels++;
         double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
         if (!replicated && world > 1 && c.opt.allreduce_max) {
             const double mine = vals[0];
-            c.opt.allreduce_max(vals, 2);
-            if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); } }
+            ex.max(vals, 2);
+            if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
         }
         if (vals[1] == 0.0) break;
     }
-    if (world > 1 && c.opt.allreduce_max) {
-        double own = (c.has_best && !c.best_x.empty()) ? -(double)rank : -INFINITY;
-        c.opt.allreduce_max(&own, 1);
-        std::vector<double> xs(nvars, -INFINITY);
-        if (own == -(double)rank && c.has_best && !c.best_x.empty()) xs = c.best_x;
-        if (own != -INFINITY) { c.opt.allreduce_max(xs.data(), nvars); c.best_x = xs; }
-    }
+    if (world > 1 && c.opt.allreduce_max && !replicated) publish_best(c, ex, nvars);
+    c.out->Aux = {(double)c.levels, (double)c.allreduces, 0.0, 0.0};
 }
 
 }  // namespace

@@ -53,6 +53,7 @@ struct SimplexResult {                  // Models/PrimalSimplex.cs:38-49
     std::vector<int32_t> NodeLog;       // B&B: (depth, outcome, branching var) per visited node
     std::vector<double> NodeZ;
     std::vector<double> Cuts;           // cutting plane: (A[0..n), B) per cut, in the order added
+    std::vector<double> Aux;            // sharded B&B: {levels, all-reduces, rebalancing rounds, node descriptors moved}
 };
 
 // The reference throws System.Exception with fixed messages; `code` is the LPX_E_* of include/lpx.h.
@@ -75,7 +76,7 @@ struct EngineOptions {
     int dual_flags = 0;              // 0 faithful (D1/D2 kept); LPX_DUAL_REPAIRED = repaired
     int bnb_mode = 0;                // 0 faithful, 1 repaired
     int bnb_search = 0;              // 0 = reference DFS (ceil first), 1 = level-synchronous sharded
-    int64_t max_nodes = 0;           // 0 = unlimited
+    int64_t max_nodes = 0;           // 0 = unlimited; sharded searches: budget of the WHOLE job (split over the ranks)
     int concurrent_nodes = 1;        // level-synchronous search: node LPs in flight per GPU
     int rank = 0, world = 1;         // level-synchronous search: shard of this process
     // incumbent exchange: called once per level with {best_z, have_work}; must return the MAX over

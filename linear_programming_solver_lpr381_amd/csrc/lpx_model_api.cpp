@@ -1,6 +1,7 @@
 // lpx_model_api.cpp -- model-level C ABI (lpx_solve, lpx_parse_text) over the C++ host mirror.
 #include "lpx_internal.h"
 #include "host/model.h"
+#include "../../include/lpx_test.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -35,6 +36,13 @@ LPProblem to_problem(const lpx_problem* p)
 
 }  // namespace
 
+// test-only stand-ins for the device loops (include/lpx_test.h); never set by a product path
+static thread_local lpx_test_seams g_seams = {nullptr, nullptr, nullptr};
+extern "C" void lpx_test_set_seams(const lpx_test_seams* s)
+{
+    if (s) g_seams = *s; else g_seams = lpx_test_seams{nullptr, nullptr, nullptr};
+}
+
 static EngineOptions to_engine(const lpx_solve_opts* o)
 {
     EngineOptions e;
@@ -48,13 +56,13 @@ static EngineOptions to_engine(const lpx_solve_opts* o)
         auto fn = o->allreduce_max; void* u = o->allreduce_user;
         e.allreduce_max = [fn, u](double* v, int n) { fn(u, v, n); };
     }
-    if (o->test_node_lp) {
-        auto fn = o->test_node_lp; void* u = o->test_user;
+    if (g_seams.node_lp) {
+        auto fn = g_seams.node_lp; void* u = g_seams.user;
         e.test_node_lp = [fn, u](double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
                                  double* x, double* z, int64_t* pivots) { return fn(u, T, R, C, basis, dual, repaired, max_iter, nvars, x, z, pivots); };
     }
-    if (o->test_knap_relax) {
-        auto fn = o->test_knap_relax; void* u = o->test_user;
+    if (g_seams.knap_relax) {
+        auto fn = g_seams.knap_relax; void* u = g_seams.user;
         e.test_knap_relax = [fn, u](int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,
                                     double* weight, int32_t* frac, double* fracval) { return fn(u, count, off, fidx, fval, profit, weight, frac, fracval); };
     }
@@ -86,6 +94,7 @@ static void fill_result(lpx_result* out, const SimplexResult& r, int nvars)
     out->lp_solves = r.LpSolves; out->nodes = r.Nodes;
     out->n_log = (int)(r.NodeLog.size() / 3); out->node_log = dup_vec(r.NodeLog); out->node_z = dup_vec(r.NodeZ);
     for (size_t i = 0; i < 4 && i < r.NodeZ.size() && r.NodeLog.empty(); ++i) out->aux[i] = r.NodeZ[i];
+    for (size_t i = 0; i < 4 && i < r.Aux.size(); ++i) out->aux[i] = r.Aux[i];
     out->stats = r.Stats;
     out->n_cuts = nvars >= 0 ? (int)(r.Cuts.size() / (size_t)(nvars + 1)) : 0; out->cuts = dup_vec(r.Cuts);
 }

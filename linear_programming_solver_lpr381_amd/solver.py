@@ -120,9 +120,7 @@ def _solve_opts(engine: dict):
             keep.append(cb)
             o.allreduce_max = cb
         elif k in ("test_node_lp", "test_knap_relax"):
-            cb = (_lib.TEST_NODE_LP if k == "test_node_lp" else _lib.TEST_KNAP_RELAX)(v)
-            keep.append(cb)
-            setattr(o, k, cb)
+            continue            # include/lpx_test.h seams: installed around the call by LPSolver.Solve
         elif hasattr(o, k):
             setattr(o, k, v)
         else:
@@ -181,7 +179,19 @@ class LPSolver:             # Models/LPSolver.cs:6-77
             o.text_cb = tcb
         ps, hold = _problem_struct(problem)
         r = _lib.Result()
-        rc = L.lpx_solve(C.byref(ps), algorithm.encode() if algorithm is not None else b"", C.byref(o), C.byref(r))
+        seams = None
+        if "test_node_lp" in self.engine or "test_knap_relax" in self.engine:      # test-only (include/lpx_test.h)
+            seams = _lib.TestSeams()
+            if "test_node_lp" in self.engine:
+                seams.node_lp = _lib.TEST_NODE_LP(self.engine["test_node_lp"])
+            if "test_knap_relax" in self.engine:
+                seams.knap_relax = _lib.TEST_KNAP_RELAX(self.engine["test_knap_relax"])
+            L.lpx_test_set_seams(C.byref(seams))
+        try:
+            rc = L.lpx_solve(C.byref(ps), algorithm.encode() if algorithm is not None else b"", C.byref(o), C.byref(r))
+        finally:
+            if seams is not None:
+                L.lpx_test_set_seams(None)
         if rc != 0:
             raise SolverException(rc, _lib.last_error())
         res = _take_result(r, problem.NumVars)

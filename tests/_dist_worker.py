@@ -77,12 +77,38 @@ def main():
     r = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, rank=rank, world=world,
                          allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p)
     res["bnb"] = {"z": r.OptimalValue, "x": r.Solution.tolist(), "lp_solves": r.LpSolves, "nodes": r.Nodes,
-                  "allreduces": calls["n"]}
+                  "allreduces": calls["n"], "aux": list(r.Aux)}
     if rank == 0:
         one = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, test_node_lp=node_lp).Solve(p)
         res["bnb_single"] = {"z": one.OptimalValue, "lp_solves": one.LpSolves}
     ref = O.bnb_solve(O.Problem(O.MAX, c, Af, np.zeros(m + n, np.int32), bf), 1)
     res["bnb_ref"] = {"z": ref.best_z, "nodes": ref.nodes_visited}
+    # --- tiny global node budgets: the budget trips while the warm-up is still replicated, or right after the hand-out;
+    #     both ranks must leave together (same number of collectives), whatever the budget
+    res["budget"] = []
+    for cap in (1, 2, 3, 4, 7, 12):
+        calls["n"] = 0
+        rb = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, rank=rank, world=world, max_nodes=cap,
+                              allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p)
+        res["budget"].append({"cap": cap, "nodes": rb.Nodes, "allreduces": calls["n"], "z": rb.OptimalValue})
+    # --- equal-z ties: two interchangeable variables (same column, same cost) give pairs of optimal solutions in
+    #     different subtrees; the published x must be the one the single-process search keeps (DFS-order key), on both ranks
+    A2 = np.hstack([A, A[:, :1]]); c2 = np.concatenate([c, c[:1]]); n2 = n + 1
+    Af2 = np.vstack([A2, np.eye(n2)]); bf2 = np.concatenate([b, np.ones(n2)])
+    p2 = L.LPProblem.from_arrays(0, c2, Af2, np.zeros(m + n2, int), bf2)
+    calls["n"] = 0
+    rt = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, rank=rank, world=world,
+                          allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p2)
+    one2 = L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, test_node_lp=node_lp).Solve(p2)
+    ref2 = O.bnb_solve(O.Problem(O.MAX, c2, Af2, np.zeros(m + n2, np.int32), bf2), 1)
+    res["ties"] = {"z": rt.OptimalValue, "x": rt.Solution.tolist(), "single_x": one2.Solution.tolist(), "single_z": one2.OptimalValue,
+                   "dfs_x": ref2.best_x.tolist(), "dfs_z": ref2.best_z, "aux": list(rt.Aux), "lp_solves": rt.LpSolves}
+    # --- rebalancing: depth-first-K pools of different fortunes; descriptors must move to the rank that runs dry
+    calls["n"] = 0
+    rr = L.BranchAndBound(bnb_mode=1, bnb_search=1, bnb_dive=1, concurrent_nodes=1, rank=rank, world=world,
+                          allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p)
+    res["rebalance"] = {"z": rr.OptimalValue, "x": rr.Solution.tolist(), "aux": list(rr.Aux), "lp_solves": rr.LpSolves,
+                        "allreduces": calls["n"]}
     # --- knapsack, sharded rounds ---
     calls["n"] = 0
     kn = 60

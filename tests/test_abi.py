@@ -11,11 +11,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "lpx.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(lpx_[a-z0-9_]+)\s*\(", hdr))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):          # lpx.h (the boundary) and lpx_test.h (test-only entry)
+        if not h.endswith(".h"):
+            continue
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(lpx_[a-z0-9_]+)\s*\(", hdr))
     names -= {"lpx_pivot_cb"}
     return sorted(names)
+
+
+def test_boundary_header_carries_no_test_hooks():
+    """The struct every host must mirror (lpx_solve_opts) has no test seam in it; the stand-ins of the CPU test-suite
+    live behind include/lpx_test.h and nothing in the package installs them except when a test asks for it."""
+    hdr = open(os.path.join(ROOT, "include", "lpx.h")).read()
+    assert "test_node_lp" not in hdr and "test_knap_relax" not in hdr and "lpx_test_set_seams" not in hdr
+    assert "lpx_test_set_seams" in open(os.path.join(ROOT, "include", "lpx_test.h")).read()
 
 
 def test_header_declares_something():

@@ -50,6 +50,22 @@ def test_world2_gloo_bnb_and_knapsack(tmp_path, lpx, oracle):
     single = res[0]["bnb_single"]
     assert single["z"] == res[0]["bnb"]["z"]
     assert tot <= 2 * single["lp_solves"] + 8
+    # tiny GLOBAL node budgets (1..12): both ranks stop together -- same number of collectives, no hang -- and the
+    # job as a whole stays within the budget (+ world - 1 for the rounding of the split)
+    for b0, b1 in zip(res[0]["budget"], res[1]["budget"]):
+        assert b0["cap"] == b1["cap"] and b0["allreduces"] == b1["allreduces"], (b0, b1)
+        assert b0["nodes"] + b1["nodes"] <= b0["cap"] + 1, (b0, b1)
+    # equal-z ties: both ranks publish the same x, it is the x of the single-process search, and its objective is the DFS optimum
+    t0, t1 = res[0]["ties"], res[1]["ties"]
+    assert t0["z"] == t1["z"] == t0["single_z"] == t0["dfs_z"]
+    assert t0["x"] == t1["x"] == t0["single_x"] == t0["dfs_x"]      # ... and the vector the reference's depth-first order finds first
+    # rebalancing: with one node per round and rank the pools drift apart; descriptors moved, every rank kept working,
+    # and the optimum is unchanged
+    r0, r1 = res[0]["rebalance"], res[1]["rebalance"]
+    assert r0["z"] == r1["z"] == res[0]["bnb_ref"]["z"] and r0["x"] == r1["x"]
+    assert r0["allreduces"] == r1["allreduces"]
+    assert r0["aux"][2] >= 1 and r0["aux"][3] >= 1 and r0["aux"][2:] == r1["aux"][2:]      # same plan on both ranks
+    assert min(r0["lp_solves"], r1["lp_solves"]) >= 0.25 * max(r0["lp_solves"], r1["lp_solves"])
 
 
 def test_single_process_level_search_with_seam_matches_oracle(lpx, oracle):
