@@ -253,6 +253,16 @@ int  lpx_knapsack_relax_batch2(lpx_knapsack* k, int count, const int32_t* off, c
                                const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
                                double* frac_val);
 int  lpx_knapsack_has_prefix(lpx_knapsack* k);
+/* Device-resident node store: the best-first loop makes every node as "its parent plus one decision" (:207-209, :267-269), so
+ * fixed lists never travel.  Job j derives the node `parent[j]` (-1 = the root, nothing fixed; else an id returned earlier)
+ * + `item[j]` fixed to `val[j]`, keeps its list in HBM under the new id child[j], and returns what lpx_knapsack_relax_batch2
+ * returns for it: slot 3j the node itself, 3j+1 / 3j+2 the node with its fractional item fixed to 0 / 1 -- whose lists are
+ * stored too, under the ids child[j] + 1 / child[j] + 2 (meaningful when frac_idx[3j] >= 0).  48 bytes go to the device per
+ * job instead of the whole list.  Needs non-negative weights (lpx_knapsack_has_prefix). */
+int  lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val,
+                               int64_t* child, double* profit, double* weight, int32_t* frac_idx, double* frac_val);
+/* The stored list of a node (ORIGINAL item indices ascending, values 0/1); *depth = its length. */
+int  lpx_knapsack_node_list(lpx_knapsack* k, int64_t node, int32_t* idx, int8_t* val, int cap, int* depth);
 
 /* ---- model level: the reference's plugin boundary through a C ABI ------------------------------ */
 /* `ILPAlgorithm.Solve(LPProblem, Action<string,bool[,]>) -> SimplexResult` (Models/IPLAlgorithm.cs:5-8)

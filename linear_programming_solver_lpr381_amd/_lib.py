@@ -173,6 +173,9 @@ def lib() -> C.CDLL:
     L.lpx_knapsack_relax_batch2.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
     L.lpx_test_set_seams.argtypes = [C.POINTER(TestSeams)]
     L.lpx_test_set_seams.restype = None
+    L.lpx_knapsack_expand_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int8), C.POINTER(C.c_int64),
+                                            dp, dp, ip, dp]
+    L.lpx_knapsack_node_list.argtypes = [vp, C.c_int64, ip, C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_int)]
     L.lpx_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
     L.lpx_default_solve_opts.restype = None
     L.lpx_solve.argtypes = [C.POINTER(Problem), C.c_char_p, C.POINTER(SolveOpts), C.POINTER(Result)]

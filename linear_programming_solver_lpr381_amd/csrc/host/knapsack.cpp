@@ -32,10 +32,23 @@ std::string last_error() { char b[1024]; lpx_last_error(b, sizeof(b)); return b;
 struct Relax { double profit = 0, weight = 0, fracval = 0; int frac = -1; bool valid = false; };
 
 struct KNode {
-    std::vector<int32_t> idx; std::vector<int8_t> val;      // fixed decisions, ascending item index
+    // a node is its parent plus one decision (:207-209, :267-269); the fixed list itself lives in the device store
+    // (lpx_knapsack_expand_batch) under `dev`, or is rebuilt from this chain when a host-side list is needed
+    KNode* parent = nullptr; int32_t item = -1; int8_t val = 0; int32_t depth = 0;
+    int64_t dev = -1;                                      // id in the device store (-1 = the root / no store)
+    int64_t child_dev[2] = {-1, -1};                       // store ids of the evaluated children
+    int64_t gchild_dev[2][2] = {{-1, -1}, {-1, -1}};       // ... and of their children (same launch)
     double bound = 0; Relax self;                          // own relaxation (bound == self.profit)
     Relax child[2];                                        // cached children (x=0, x=1)
     Relax gchild[2][2];                                    // cached children of child v (lpx_knapsack_relax_batch2)
+    // fixed decisions in ascending item index (the reference's Assigned without the undecided entries)
+    void list(std::vector<int32_t>& idx, std::vector<int8_t>& val) const {
+        std::vector<std::pair<int32_t, int8_t>> e; e.reserve((size_t)depth);
+        for (const KNode* p = this; p && p->item >= 0; p = p->parent) e.emplace_back(p->item, p->val);
+        std::sort(e.begin(), e.end());
+        idx.clear(); val.clear();
+        for (auto& x : e) { idx.push_back(x.first); val.push_back(x.second); }
+    }
 };
 using NodeP = std::unique_ptr<KNode>;
 
@@ -77,28 +90,41 @@ struct Search {
     // evaluates `jobs` = (node, fixed item, value) in one launch
     struct Job { KNode* node; int item; int v; Relax* out; Relax* gout; };   // gout: two slots for the job's own children, or null
     bool depth2 = false;                                 // one launch also evaluates each job's two children
+    bool use_store = false;                              // device-resident node lists (lpx_knapsack_expand_batch)
     void run_jobs(std::vector<Job>& jobs)
     {
         if (jobs.empty()) return;
-        std::vector<int32_t> off(jobs.size() + 1, 0), fidx; std::vector<int8_t> fval;
-        for (size_t j = 0; j < jobs.size(); ++j) {
-            const KNode* nd = jobs[j].node;              // nd->idx is kept in ascending index order (:442)
-            const int it = jobs[j].item;
-            bool placed = it < 0;
-            for (size_t e = 0; e < nd->idx.size(); ++e) {
-                if (!placed && it < nd->idx[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
-                fidx.push_back(nd->idx[e]); fval.push_back(nd->val[e]);
-            }
-            if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
-            off[j + 1] = (int32_t)fidx.size();
-        }
         const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
         std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
-        if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
-        int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-               : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                        : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
-        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        if (use_store && jobs[0].item >= 0) {
+            // 32 bytes per job: (parent id, item, value); the device derives, stores and evaluates the child
+            std::vector<int64_t> par(jobs.size()), ch(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
+            for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = jobs[j].item; vv[j] = (int8_t)jobs[j].v; }
+            int rc = lpx_knapsack_expand_batch(k, (int)jobs.size(), par.data(), it.data(), vv.data(), ch.data(), p.data(), w.data(), fr.data(), fv.data());
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            for (size_t j = 0; j < jobs.size(); ++j) {
+                KNode* nd = jobs[j].node; const int v = jobs[j].v;
+                nd->child_dev[v] = ch[j]; nd->gchild_dev[v][0] = ch[j] + 1; nd->gchild_dev[v][1] = ch[j] + 2;
+            }
+        } else {
+            std::vector<int32_t> off(jobs.size() + 1, 0), fidx, li; std::vector<int8_t> fval, lv;
+            for (size_t j = 0; j < jobs.size(); ++j) {
+                jobs[j].node->list(li, lv);                  // ascending index order (:442)
+                const int it = jobs[j].item;
+                bool placed = it < 0;
+                for (size_t e = 0; e < li.size(); ++e) {
+                    if (!placed && it < li[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
+                    fidx.push_back(li[e]); fval.push_back(lv[e]);
+                }
+                if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
+                off[j + 1] = (int32_t)fidx.size();
+            }
+            if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
+            int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                   : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                            : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        }
         ++launches;
         for (size_t j = 0; j < jobs.size(); ++j) {
             Relax& r = *jobs[j].out;
@@ -118,7 +144,7 @@ struct Search {
     std::vector<double> relaxed_of(const KNode& nd, int item, int v, const Relax& r) const
     {
         std::vector<int8_t> as(n, -1);
-        for (size_t e = 0; e < nd.idx.size(); ++e) as[nd.idx[e]] = nd.val[e];
+        for (const KNode* q = &nd; q && q->item >= 0; q = q->parent) as[q->item] = q->val;
         if (item >= 0) as[item] = (int8_t)v;
         std::vector<double> x(n, 0.0);
         for (int i = 0; i < n; ++i) if (as[i] == 1) x[i] = 1.0;
@@ -153,15 +179,11 @@ struct Search {
                 }
             } else {                                                        // :239-248
                 NodeP ch(new KNode());
-                ch->idx.reserve(node->idx.size() + 1); ch->val.reserve(node->idx.size() + 1);
-                bool placed = false;                                        // keep ascending index order
-                for (size_t e = 0; e < node->idx.size(); ++e) {
-                    if (!placed && item < node->idx[e]) { ch->idx.push_back(item); ch->val.push_back((int8_t)v); placed = true; }
-                    ch->idx.push_back(node->idx[e]); ch->val.push_back(node->val[e]);
-                }
-                if (!placed) { ch->idx.push_back(item); ch->val.push_back((int8_t)v); }
+                ch->parent = node; ch->item = item; ch->val = (int8_t)v; ch->depth = node->depth + 1;
+                ch->dev = node->child_dev[v];
                 ch->bound = r.profit; ch->self = r;
                 ch->child[0] = node->gchild[v][0]; ch->child[1] = node->gchild[v][1];   // already evaluated with the parent's launch
+                ch->child_dev[0] = node->gchild_dev[v][0]; ch->child_dev[1] = node->gchild_dev[v][1];
                 pq.push(ch.get());
                 store.push_back(std::move(ch));
                 max_heap = std::max<int64_t>(max_heap, (int64_t)pq.d.size());
@@ -250,12 +272,16 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     {   // every launch also evaluates the children of the nodes it evaluates (LPX_KNAP_DEPTH2=0: off)
         const char* e = std::getenv("LPX_KNAP_DEPTH2");
         S.depth2 = !S.test_relax && kh && lpx_knapsack_has_prefix(kh) && !(e && e[0] == '0');
+        // node lists resident on the device (LPX_KNAP_STORE=0: every job ships its whole list, the r01 path)
+        const char* e2 = std::getenv("LPX_KNAP_STORE");
+        S.use_store = S.depth2 && !(e2 && e2[0] == '0');
     }
 
     std::vector<NodeP> store;
     Heap pq;
     NodeP root(new KNode());                                                // :102-113
-    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self, root->child}}; S.run_jobs(j); S.relaxations++; }
+    // (with the device store the root's children are derived there when the root is popped, so that their lists exist)
+    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self, S.use_store ? nullptr : root->child}}; S.run_jobs(j); S.relaxations++; }
     root->bound = root->self.profit;
     pq.push(root.get()); store.push_back(std::move(root));
     S.max_heap = 1;

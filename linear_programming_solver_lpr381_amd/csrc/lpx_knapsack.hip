@@ -241,6 +241,131 @@ __global__ __launch_bounds__(256) void knap_relax_prefix(KnParams P, KnPrefix X)
     solve(frac, 1, xw, xp, 3 * node + 2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident node store.  The best-first loop creates every node as "its parent plus one decision"
+// (Models/BranchAndBoundKnapsack.cs:207-209,:267-269), so a node's fixed list never has to travel: the parent's list
+// already sits in HBM, the kernel writes the child's list next to it (ascending item index, the decision packed as
+// idx | val << 31) and evaluates the child -- and the child's own two children, as knap_relax_prefix<true> does -- from
+// the parent's entries in registers plus the new decision(s) as extras.  A job is 32 bytes of H2D instead of the whole
+// list (100-250 entries per node at config 5), and the host keeps a heap of ids.
+// ------------------------------------------------------------------------------------------------
+struct KnJob { const uint32_t* parent; uint32_t* child; uint32_t* g0; uint32_t* g1; int32_t depth; int32_t item; int32_t val; int32_t pad; };
+
+__global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const KnJob* __restrict__ jobs, const int32_t* __restrict__ ord)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wave;
+    if (job >= P.count) return;
+    const KnJob J = jobs[job];
+    const int n = P.n, d = J.depth;
+    const uint32_t* __restrict__ par = J.parent;
+    // the new decision
+    const int xi = J.item;
+    const int x1pos = P.pos[xi]; const double x1w = P.w0[xi], x1p = P.p0[xi]; const int x1val = J.val;
+    int cpos[KP_CACHE]; double cw[KP_CACHE], cp[KP_CACHE];
+    double w1 = 0.0, p1 = 0.0;
+    int before = 0;                                     // parent entries with a smaller item index (insertion point)
+#pragma unroll
+    for (int k = 0; k < KP_CACHE; ++k) {
+        const int e = lane + 64 * k;
+        cpos[k] = INT_MAX; cw[k] = 0.0; cp[k] = 0.0;
+        if (e < d) {
+            const uint32_t v = par[e];
+            const int i = (int)(v & 0x7fffffffu);
+            cpos[k] = P.pos[i]; cw[k] = P.w0[i]; cp[k] = P.p0[i];
+            if (v >> 31) { w1 += cw[k]; p1 += cp[k]; }
+            before += (i < xi) ? 1 : 0;
+            J.child[e + ((i > xi) ? 1 : 0)] = v;
+        }
+    }
+    for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {            // deeper nodes: the tail stays in memory
+        const uint32_t v = par[e];
+        const int i = (int)(v & 0x7fffffffu);
+        if (v >> 31) { w1 += P.w0[i]; p1 += P.p0[i]; }
+        before += (i < xi) ? 1 : 0;
+        J.child[e + ((i > xi) ? 1 : 0)] = v;
+    }
+    before = (int)wave_sum_f64((double)before);
+    if (lane == 0) J.child[before] = (uint32_t)xi | ((uint32_t)x1val << 31);
+    const double W1n = wave_sum_f64(w1) + (x1val == 1 ? x1w : 0.0), P1n = wave_sum_f64(p1) + (x1val == 1 ? x1p : 0.0);
+
+    auto solve = [&](int xpos, int xval, double xw, double xp, int slot) {
+        const double W1 = W1n + (xval == 1 ? xw : 0.0), P1 = P1n + (xval == 1 ? xp : 0.0);
+        if (W1 > P.cap + KEPS) {                                        // :455-456
+            if (lane == 0) { P.out_profit[slot] = P1; P.out_weight[slot] = W1; P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0; }
+            return -1;
+        }
+        auto fixed_before = [&](int t, double& fw, double& fp) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP_CACHE; ++k) if (cpos[k] < t) { a += cw[k]; b += cp[k]; }
+            for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {
+                const int i = (int)(par[e] & 0x7fffffffu);
+                if (P.pos[i] < t) { a += P.w0[i]; b += P.p0[i]; }
+            }
+            fw = wave_sum_f64(a); fp = wave_sum_f64(b);
+            if (x1pos < t) { fw += x1w; fp += x1p; }
+            if (xpos < t) { fw += xw; fp += xp; }
+        };
+        int lo = 1, hi = n + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            double fw, fp;
+            fixed_before(mid, fw, fp);
+            if (W1 + (X.PW[mid] - fw) > P.cap + KEPS) hi = mid; else lo = mid + 1;
+        }
+        double fw, fp;
+        if (lo == n + 1) {
+            fixed_before(n, fw, fp);
+            if (lane == 0) {
+                P.out_profit[slot] = P1 + (X.PP[n] - fp); P.out_weight[slot] = W1 + (X.PW[n] - fw);
+                P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0;
+            }
+            return -1;
+        }
+        const int j = lo - 1;
+        fixed_before(j, fw, fp);
+        double w = W1 + (X.PW[j] - fw), p = P1 + (X.PP[j] - fp);
+        int frac = -1; double fv = 0.0;
+        const double wi = P.ws[j];
+        const double remain = P.cap - w;
+        if (remain > KEPS && wi > KEPS) {                               // :476-484
+            fv = remain / wi;
+            p += P.ps[j] * fv;
+            w += wi * fv;
+            frac = j;
+        }
+        if (lane == 0) { P.out_profit[slot] = p; P.out_weight[slot] = w; P.out_frac[slot] = frac; P.out_fracval[slot] = fv; }
+        return frac;
+    };
+    const int frac = solve(INT_MAX, 0, 0.0, 0.0, 3 * job);
+    if (frac < 0) {
+        if (lane == 0) { P.out_frac[3 * job + 1] = -2; P.out_frac[3 * job + 2] = -2; }
+        return;
+    }
+    const double xw = P.ws[frac], xp = P.ps[frac];
+    solve(frac, 0, xw, xp, 3 * job + 1);
+    solve(frac, 1, xw, xp, 3 * job + 2);
+    // the lists of those two children (the child's list plus its fractional item, value 0 / 1): every relaxation the host
+    // caches has its node in the store, so the host never has to send a list
+    const int x2 = ord[frac];
+    int before2 = 0;
+    for (int e = lane; e < d; e += 64) {
+        const uint32_t v = par[e];
+        const int i = (int)(v & 0x7fffffffu);
+        before2 += (i < x2) ? 1 : 0;
+        const int dst = e + ((i > xi) ? 1 : 0) + ((i > x2) ? 1 : 0);
+        J.g0[dst] = v; J.g1[dst] = v;
+    }
+    before2 = (int)wave_sum_f64((double)before2);
+    if (lane == 0) {
+        const int p1 = before + ((xi > x2) ? 1 : 0), p2 = before2 + ((x2 > xi) ? 1 : 0);
+        const uint32_t e1 = (uint32_t)xi | ((uint32_t)x1val << 31);
+        J.g0[p1] = e1; J.g1[p1] = e1;
+        J.g0[p2] = (uint32_t)x2; J.g1[p2] = (uint32_t)x2 | 0x80000000u;
+    }
+}
+
 }  // namespace lpx
 
 using namespace lpx;
@@ -259,7 +384,14 @@ struct lpx_knapsack {
     char* d_in = nullptr; char* h_in = nullptr; size_t in_cap = 0;
     char* d_out = nullptr; char* h_out = nullptr; size_t out_cap = 0;
     hipStream_t stream = nullptr;
+    // device-resident node store (lpx_knapsack_expand_batch): bump-allocated lists in 64 MiB chunks
+    std::vector<uint32_t*> chunks; size_t chunk_used = 0;
+    std::vector<uint32_t*> node_list; std::vector<int32_t> node_depth;      // node id -> (list, depth)
+    char* d_jobs = nullptr; char* h_jobs = nullptr; size_t jobs_cap = 0;
+    int32_t* d_ord = nullptr;                                                // ratio rank -> original index
 };
+
+static constexpr size_t KN_CHUNK_WORDS = (size_t)16 << 20;                   // 64 MiB of uint32
 
 extern "C" {
 
@@ -270,7 +402,9 @@ void lpx_knapsack_destroy(lpx_knapsack* k)
     hipFree(k->ws); hipFree(k->ps); hipFree(k->w0); hipFree(k->p0); hipFree(k->pos); hipFree(k->PW); hipFree(k->PP);
     hipFree(k->d_off); hipFree(k->d_fidx); hipFree(k->d_frac); hipFree(k->d_fval);
     hipFree(k->d_profit); hipFree(k->d_weight); hipFree(k->d_fracval);
-    hipFree(k->d_in); hipFree(k->d_out);
+    hipFree(k->d_in); hipFree(k->d_out); hipFree(k->d_jobs); hipFree(k->d_ord);
+    for (uint32_t* c : k->chunks) hipFree(c);
+    if (k->h_jobs) hipHostFree(k->h_jobs);
     if (k->h_in) hipHostFree(k->h_in);
     if (k->h_out) hipHostFree(k->h_out);
     delete k;
@@ -310,6 +444,7 @@ int lpx_knapsack_create(const double* profit, const double* weight, int n, doubl
     up((void**)&k->ws, ws.data(), sizeof(double) * n); up((void**)&k->ps, ps.data(), sizeof(double) * n);
     up((void**)&k->w0, weight, sizeof(double) * n); up((void**)&k->p0, profit, sizeof(double) * n);
     up((void**)&k->pos, pos.data(), sizeof(int32_t) * n);
+    up((void**)&k->d_ord, k->order.data(), sizeof(int32_t) * n);
     // running sums in ratio order (left-to-right, as the reference accumulates) for the prefix-sum kernel
     std::vector<double> PW(n + 1, 0.0), PP(n + 1, 0.0);
     bool nonneg = true;
@@ -409,5 +544,98 @@ int lpx_knapsack_relax_batch2(lpx_knapsack* k, int count, const int32_t* off, co
 }
 
 int lpx_knapsack_has_prefix(lpx_knapsack* k) { return k && k->prefix_ok ? 1 : 0; }
+
+int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val,
+                              int64_t* child, double* profit, double* weight, int32_t* frac_idx, double* frac_val)
+{
+    if (!k || count < 0 || (count > 0 && (!parent || !item || !val || !child))) { set_error("lpx_knapsack_expand_batch: bad argument"); return LPX_EINVAL; }
+    if (!k->prefix_ok) { set_error("lpx_knapsack_expand_batch needs the prefix-sum path (non-negative weights)"); return LPX_EINVAL; }
+    if (count == 0) return 0;
+    const int64_t known = (int64_t)k->node_list.size();
+    for (int j = 0; j < count; ++j) {
+        if (parent[j] < -1 || parent[j] >= known || item[j] < 0 || item[j] >= k->n || (val[j] != 0 && val[j] != 1)) {
+            set_error("lpx_knapsack_expand_batch: parent id, item or value out of range"); return LPX_EINVAL; }
+    }
+    const size_t jb = sizeof(KnJob) * (size_t)count;
+    if (jb > k->jobs_cap) {
+        hipFree(k->d_jobs); if (k->h_jobs) hipHostFree(k->h_jobs);
+        k->d_jobs = nullptr; k->h_jobs = nullptr; k->jobs_cap = 0;
+        const size_t c = 2 * jb + 4096;
+        LPX_HIP_TRY(hipMalloc((void**)&k->d_jobs, c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&k->h_jobs, c));
+        k->jobs_cap = c;
+    }
+    KnJob* hj = reinterpret_cast<KnJob*>(k->h_jobs);
+    auto carve = [&](size_t words, uint32_t** out) -> int {
+        const size_t need = (words + 3) & ~(size_t)3;                        // 16-byte granules
+        if (need > KN_CHUNK_WORDS) { set_error("lpx_knapsack_expand_batch: node deeper than a store chunk"); return LPX_EINVAL; }
+        if (k->chunks.empty() || k->chunk_used + need > KN_CHUNK_WORDS) {
+            uint32_t* c = nullptr;
+            if (hipMalloc((void**)&c, sizeof(uint32_t) * KN_CHUNK_WORDS) != hipSuccess) { set_error("lpx_knapsack_expand_batch: out of device memory for the node store"); return LPX_ENOMEM; }
+            k->chunks.push_back(c); k->chunk_used = 0;
+        }
+        *out = k->chunks.back() + k->chunk_used;
+        k->chunk_used += need;
+        return 0;
+    };
+    for (int j = 0; j < count; ++j) {
+        const int d = parent[j] < 0 ? 0 : k->node_depth[(size_t)parent[j]];
+        uint32_t *c0 = nullptr, *g0 = nullptr, *g1 = nullptr;
+        int rc = carve((size_t)d + 1, &c0); if (rc) return rc;
+        rc = carve((size_t)d + 2, &g0); if (rc) return rc;
+        rc = carve((size_t)d + 2, &g1); if (rc) return rc;
+        hj[j].parent = parent[j] < 0 ? c0 : k->node_list[(size_t)parent[j]];    // depth 0: never dereferenced
+        hj[j].child = c0; hj[j].g0 = g0; hj[j].g1 = g1; hj[j].depth = d; hj[j].item = item[j]; hj[j].val = val[j]; hj[j].pad = 0;
+        child[j] = (int64_t)k->node_list.size();                             // ids child[j] + 1 / + 2: its two children (if any)
+        k->node_list.push_back(c0); k->node_depth.push_back(d + 1);
+        k->node_list.push_back(g0); k->node_depth.push_back(d + 2);
+        k->node_list.push_back(g1); k->node_depth.push_back(d + 2);
+    }
+    const int nout = 3 * count;
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_p = 0, o_w = sizeof(double) * nout, o_fv = 2 * sizeof(double) * nout, o_fr = 3 * sizeof(double) * nout;
+    const size_t out_bytes = o_fr + up8(sizeof(int32_t) * nout);
+    if (out_bytes > k->out_cap) {
+        hipFree(k->d_out); if (k->h_out) hipHostFree(k->h_out);
+        k->d_out = nullptr; k->h_out = nullptr; k->out_cap = 0;
+        const size_t c = 2 * out_bytes + 4096;
+        LPX_HIP_TRY(hipMalloc((void**)&k->d_out, c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&k->h_out, c));
+        k->out_cap = c;
+    }
+    // Zero-copy: the kernel reads its 48-byte job records from, and writes its results to, pinned host memory directly
+    // (hipHostMalloc memory is device-visible and coherent).  A batch is then ONE launch and one wait instead of
+    // copy + launch + copy + wait: the loop is bound by that round trip, not by bytes (a few KB per batch).
+    hipStream_t s = k->stream;
+    KnParams P;
+    P.n = k->n; P.cap = k->cap; P.ws = k->ws; P.ps = k->ps; P.pos = k->pos; P.w0 = k->w0; P.p0 = k->p0;
+    P.count = count; P.off = nullptr; P.fidx = nullptr; P.fval = nullptr;
+    P.out_profit = reinterpret_cast<double*>(k->h_out + o_p); P.out_weight = reinterpret_cast<double*>(k->h_out + o_w);
+    P.out_fracval = reinterpret_cast<double*>(k->h_out + o_fv); P.out_frac = reinterpret_cast<int32_t*>(k->h_out + o_fr);
+    KnPrefix X; X.PW = k->PW; X.PP = k->PP;
+    hipLaunchKernelGGL(knap_expand, dim3((count + 3) / 4), dim3(256), 0, s, P, X, reinterpret_cast<const KnJob*>(k->h_jobs), (const int32_t*)k->d_ord);
+    LPX_HIP_TRY(hipGetLastError());
+    LPX_HIP_TRY(hipStreamSynchronize(s));
+    if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * nout);
+    if (weight) std::memcpy(weight, k->h_out + o_w, sizeof(double) * nout);
+    if (frac_val) std::memcpy(frac_val, k->h_out + o_fv, sizeof(double) * nout);
+    if (frac_idx) std::memcpy(frac_idx, k->h_out + o_fr, sizeof(int32_t) * nout);
+    return 0;
+}
+
+int lpx_knapsack_node_list(lpx_knapsack* k, int64_t node, int32_t* idx, int8_t* val, int cap, int* depth)
+{
+    if (!k || node < 0 || node >= (int64_t)k->node_list.size()) { set_error("lpx_knapsack_node_list: unknown node id"); return LPX_EINVAL; }
+    const int d = k->node_depth[(size_t)node];
+    if (depth) *depth = d;
+    if (idx && val && cap > 0) {
+        const int c = d < cap ? d : cap;
+        std::vector<uint32_t> tmp((size_t)(c > 0 ? c : 1));
+        LPX_HIP_TRY(hipStreamSynchronize(k->stream));
+        if (c > 0) LPX_HIP_TRY(hipMemcpy(tmp.data(), k->node_list[(size_t)node], sizeof(uint32_t) * c, hipMemcpyDeviceToHost));
+        for (int e = 0; e < c; ++e) { idx[e] = (int32_t)(tmp[e] & 0x7fffffffu); val[e] = (int8_t)(tmp[e] >> 31); }
+    }
+    return 0;
+}
 
 }  // extern "C"

@@ -381,6 +381,30 @@ class DeviceKnapsack:
                                                    fx.ctypes.data_as(_lib.dp)))
         return p.reshape(k, 3), w.reshape(k, 3), fr.reshape(k, 3), fx.reshape(k, 3)
 
+    def expand_batch(self, parents, items, vals):
+        """lpx_knapsack_expand_batch: node j = stored node parents[j] (-1 = root) + items[j] fixed to vals[j]; its list stays
+        on the device.  Returns (ids, profit, weight, frac, fracval) with the last four of shape (len, 3) as relax_batch2;
+        ids[j] + 1 / + 2 are the stored children of node j (fractional item fixed to 0 / 1)."""
+        k = len(parents)
+        par = np.asarray(parents, np.int64); it = np.asarray(items, np.int32); vv = np.asarray(vals, np.int8)
+        ids = np.zeros(k, np.int64)
+        p = np.zeros(3 * k); w = np.zeros(3 * k); fr = np.zeros(3 * k, np.int32); fx = np.zeros(3 * k)
+        _lib.check(lib().lpx_knapsack_expand_batch(self._h, k, par.ctypes.data_as(C.POINTER(C.c_int64)), it.ctypes.data_as(_lib.ip),
+                                                   vv.ctypes.data_as(C.POINTER(C.c_int8)), ids.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   p.ctypes.data_as(_lib.dp), w.ctypes.data_as(_lib.dp), fr.ctypes.data_as(_lib.ip),
+                                                   fx.ctypes.data_as(_lib.dp)))
+        return ids, p.reshape(k, 3), w.reshape(k, 3), fr.reshape(k, 3), fx.reshape(k, 3)
+
+    def node_list(self, node: int) -> dict:
+        """The stored fixed list of a node as {item: 0/1}."""
+        d = C.c_int()
+        _lib.check(lib().lpx_knapsack_node_list(self._h, int(node), None, None, 0, C.byref(d)))
+        idx = np.zeros(max(d.value, 1), np.int32); val = np.zeros(max(d.value, 1), np.int8)
+        _lib.check(lib().lpx_knapsack_node_list(self._h, int(node), idx.ctypes.data_as(_lib.ip), val.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                d.value, C.byref(d)))
+        assert list(idx[: d.value]) == sorted(idx[: d.value])
+        return {int(i): int(v) for i, v in zip(idx[: d.value], val[: d.value])}
+
     def relax_batch(self, nodes):
         """nodes: list of dict {item_index: 0/1}. Returns (profit, weight, frac_sorted_idx, frac_value)."""
         off = [0]

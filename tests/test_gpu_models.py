@@ -326,3 +326,86 @@ def test_bnb_dive_policy_reaches_the_same_optimum(gpu, oracle, search):
         r = gpu.BranchAndBound(bnb_mode=1, bnb_search=search, bnb_dive=1, concurrent_nodes=3).Solve(p)
         assert abs(r.OptimalValue - ref.best_z) <= 1e-9 * abs(ref.best_z), (search, trial)
         assert abs(np.asarray(r.Solution) @ c - ref.best_z) <= 1e-9 * abs(ref.best_z)
+
+
+def test_knapsack_device_node_store_expand_batch(gpu, oracle):
+    """lpx_knapsack_expand_batch: nodes are derived on the device from a stored parent plus one decision; the stored lists
+    (ascending item index) and the three relaxations per job equal what lpx_knapsack_relax_batch2 / the oracle give for
+    the same fixed sets -- random chains 300+ deep (past the 256 register-cached entries), several generations per store."""
+    g = np.random.default_rng(77)
+    for n in (7, 60, 900, 5000):
+        w = g.integers(1, 1001, size=n).astype(float)
+        p = w + g.integers(0, 101, size=n)
+        cap = float(np.floor(0.5 * w.sum()))
+        dk = gpu.DeviceKnapsack(p, w, cap)
+        order = oracle.knapsack_order(p, w)
+        known = {-1: {}}                                   # id -> fixed dict
+        frontier = [-1]
+        for gen in range(min(n - 1, 330)):
+            parents, items, vals = [], [], []
+            for par in frontier[:6]:
+                free = [i for i in g.choice(n, size=min(n, 8), replace=False) if int(i) not in known[par]]
+                if not free:
+                    continue
+                parents.append(par); items.append(int(free[0])); vals.append(int(g.integers(0, 4) == 0))
+            if not parents:
+                break
+            ids, P, W, F, X = dk.expand_batch(parents, items, vals)
+            nodes = []
+            for j, (par, it, v) in enumerate(zip(parents, items, vals)):
+                fx = dict(known[par]); fx[it] = v
+                known[int(ids[j])] = fx
+                nodes.append(fx)
+                if gen % 40 == 0 or gen > 320:
+                    assert dk.node_list(int(ids[j])) == fx, (n, gen, j)
+                if F[j, 0] >= 0:                           # stored children: node + fractional item fixed to 0 / 1
+                    item2 = int(order[F[j, 0]])
+                    for c in (0, 1):
+                        fx2 = dict(fx); fx2[item2] = c
+                        known[int(ids[j]) + 1 + c] = fx2
+                        if gen % 40 == 0:
+                            assert dk.node_list(int(ids[j]) + 1 + c) == fx2
+            P2, W2, F2, X2 = dk.relax_batch2(nodes)
+            live = F != -2                                  # slots of children that do not exist carry no numbers
+            assert np.array_equal(F, F2) and np.array_equal(P[live], P2[live]) and np.array_equal(W[live], W2[live]), (n, gen)
+            assert np.array_equal(X[live], X2[live]), (n, gen)
+            if gen % 25 == 0:
+                for j, nd in enumerate(nodes):
+                    a = -np.ones(n, np.int32)
+                    for i, v in nd.items():
+                        a[i] = v
+                    rp, rw, rf, rx = oracle.knapsack_relax(p, w, cap, order, a, want_vector=True)
+                    assert (P[j, 0], W[j, 0], F[j, 0]) == (rp, rw, rf), (n, gen, j)
+            # next generation: mix of plain children and stored depth-2 children
+            nxt = [int(i) for i in ids]
+            nxt += [int(ids[j]) + 1 + int(g.integers(0, 2)) for j in range(len(ids)) if F[j, 0] >= 0][:3]
+            frontier = nxt
+        dk.close()
+
+
+def test_knapsack_solve_same_counts_with_and_without_the_device_store(oracle):
+    """LPX_KNAP_STORE=0 (every job ships its list, the r01 path) and the device-resident store give the same search."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, json
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        p, w, cap = synth.knapsack(20000, seed=5)
+        kp = L.LPProblem(L.Sense.Max, p.tolist(), [L.Constraint(w.tolist(), L.Rel.LE, cap)])
+        r = L.BranchAndBoundKnapsack(max_nodes=6000).Solve(kp)
+        print(json.dumps([r.Nodes, r.Aux[0], r.Aux[2], r.Aux[3], r.OptimalValue if np.isfinite(r.OptimalValue) else None,
+                          r.Extra.astype(int).tolist() if np.isfinite(r.OptimalValue) else None]))
+    ''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for store in ("1", "0"):
+        env = dict(os.environ, LPX_KNAP_STORE=store, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+    p, w, cap = synth.knapsack(20000, seed=5)
+    ref = oracle.knapsack_solve(oracle.Problem(oracle.MAX, p, w.reshape(1, -1), [oracle.LE], [cap]), max_nodes=6000)
+    import json
+    got = json.loads(outs[0])
+    assert got[0] == ref.nodes_popped and got[1] == ref.relaxations and got[2] == ref.nodes_expanded
