@@ -254,7 +254,10 @@ __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const S
 // chain is replayed over the <= 64 segment records by every lane.  A segment that would be entered through a tie / near-tie
 // hands over to the exact sequential scan from that segment on (carried best and position included): same winner, always.
 // All NW*64 lanes call this; one barrier.
-template <int NW, class Src>
+// WAVE0_REPLAY: the exact replay after a tie runs on wave 0 only and is broadcast (single-workgroup kernels whose sources are
+// strided gathers, and 0/1 programs whose dual ratios tie at 0 all the time: 16 waves replaying would multiply the traffic);
+// false: every wave replays for itself, no second barrier (multi-workgroup select, where every wave did the whole scan before).
+template <int NW, class Src, bool WAVE0_REPLAY = false>
 __device__ __forceinline__ int block_hysteresis_segments(int L, double tol, const Src& src)
 {
     constexpr int SEG = 64 * WH_PER;
@@ -294,7 +297,13 @@ __device__ __forceinline__ int block_hysteresis_segments(int L, double tol, cons
         const double v = sg_v[sgi];
         if (!(v < best - tol)) continue;                 // nothing in this segment beats the carried best
         const int i = sg_i[sgi];
-        if (i < 0) return wave_hysteresis_argmin(L, tol, src, sgi * SEG, best, win);    // ties: exact scan from here on
+        if (i < 0) {                                     // ties: exact scan from here on (the decision is workgroup-uniform)
+            if constexpr (!WAVE0_REPLAY) return wave_hysteresis_argmin(L, tol, src, sgi * SEG, best, win);
+            __shared__ int sg_out;
+            if (wave == 0) { const int w = wave_hysteresis_argmin(L, tol, src, sgi * SEG, best, win); if (lane == 0) sg_out = w; }
+            __syncthreads();
+            return sg_out;
+        }
         best = v; win = i;
     }
     return win;
@@ -311,6 +320,17 @@ __device__ __forceinline__ int block_hysteresis_argmin(int L, double tol, const 
     __syncthreads();
     const int r = *s_out;
     __syncthreads();                                    // s_out may be reused by the next scan
+    return r;
+}
+
+// single-workgroup kernels: one segment -> wave 0 scans and the others wait (16 waves gathering the same strided column
+// would only multiply the traffic); longer vectors -> the segments spread over all NW waves
+template <int NW, class Src>
+__device__ __forceinline__ int block_hysteresis_auto(int L, double tol, const Src& src, int* s_out)
+{
+    if (L <= 64 * WH_PER || L > 64 * 64 * WH_PER) return block_hysteresis_argmin(L, tol, src, s_out);
+    const int r = block_hysteresis_segments<NW, Src, true>(L, tol, src);
+    __syncthreads();                                    // its segment records may be reused by the next scan
     return r;
 }
 

@@ -66,6 +66,8 @@ hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = n
 int select_mb_blocks(int C);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s);
 hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s);
+hipError_t launch_group_rhs_init(const SelParams* arr, int count, hipStream_t s);     // dual groups: contiguous RHS copy
+hipError_t launch_rhs_init(const SelParams& p, hipStream_t s);
 int update_blocks(int ld, int R);
 hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
                               int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s);

@@ -20,7 +20,6 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
     __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
     __shared__ int s_i[SEL_NW];
-    __shared__ double s_piv;
 
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;              // uniform: loop already finished
@@ -31,6 +30,9 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
     const int rhs = C - 1;
     const size_t ld = (size_t)P.ld;
     double* T = P.T;
+    // contiguous copy of the RHS column: filled once per run by lpx_rhs_init, kept current by lpx_update (rows i != r)
+    // and by this kernel (row r) -- the dual loop's leaving-row scan and every ratio test read it instead of a strided column
+    const double* rhsb = P.rhsbuf;
 
     int phase = st->phase;
     const int fdf_count = st->fdf_count, dual_iter = st->dual_iter, primal_count = st->primal_count;
@@ -46,12 +48,12 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
                 if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { phase = 1; continue; }
-                r = block_hysteresis_argmin(m, P.tol_fdf, RowRatio{T + q, ld, T + rhs, ld, P.eps}, &s_out);
+                r = block_hysteresis_auto<SEL_NW>(m, P.tol_fdf, RowRatio{T + q, ld, rhsb, 1, P.eps}, &s_out);
                 if (r < 0) { q = -1; phase = 1; continue; }
             } else if (phase == 1) {
                 // dual loop, Models/DualSimplex.cs:36-113
                 if (dual_iter >= P.max_iter) { final_status = LPX_ITER_LIMIT; break; }
-                r = block_first_min_below(T + rhs, ld, m, P.eps, s_v, s_i);
+                r = block_first_min_below(rhsb, 1, m, P.eps, s_v, s_i);
                 if (r < 0) {
                     if (P.cleanup) {
                         int qe = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
@@ -59,14 +61,14 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
                     }
                     final_status = LPX_OPTIMAL; break;
                 }
-                q = block_hysteresis_argmin(rhs, P.tol_dual, DualColRatio{T + (size_t)r * ld, T + (size_t)m * ld, P.eps}, &s_out);
+                q = block_hysteresis_auto<SEL_NW>(rhs, P.tol_dual, DualColRatio{T + (size_t)r * ld, T + (size_t)m * ld, P.eps}, &s_out);
                 if (q < 0) { r = -1; final_status = LPX_INFEASIBLE; break; }
             } else {
                 // primal loop, Models/PrimalSimplex.cs:92-124
                 if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { final_status = LPX_OPTIMAL; break; }
-                r = block_hysteresis_argmin(m, P.tol_primal, RowRatio{T + q, ld, T + rhs, ld, P.eps}, &s_out);
+                r = block_hysteresis_auto<SEL_NW>(m, P.tol_primal, RowRatio{T + q, ld, rhsb, 1, P.eps}, &s_out);
                 if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
             }
         }
@@ -82,17 +84,16 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
 
     // ---- pivot prep (Models/PrimalSimplex.cs:249-250, :254): snapshot the pivot column, normalise
     // the pivot row in place and into `prow` so the update kernel never reads what it overwrites.
-    if (t == 0) s_piv = T[(size_t)r * ld + q];
-    __syncthreads();
-    const double piv = s_piv;
+    const double piv = T[(size_t)r * ld + q];          // one address for the whole workgroup: a broadcast load
     for (int i = t; i < R; i += SEL_NT)
         P.pcol[i] = (i == r) ? 0.0 : T[(size_t)i * ld + q];
-    __syncthreads();                                   // column read before the row is rewritten
+    __syncthreads();                                   // pivot and column read before the row is rewritten
     double* trow = T + (size_t)r * ld;
     for (int j = t; j < C; j += SEL_NT) {
         double p = trow[j] / piv;
         trow[j] = p;
         P.prow[j] = p;
+        if (j == rhs) P.rhsbuf[r] = p;                 // lpx_update leaves row r alone
     }
     if (t == 0) {
         P.basis[r] = q;                                // basis[leaving] = entering, :110
@@ -103,6 +104,13 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
         else if (phase == 1) st->dual_iter = dual_iter + 1;
         else st->primal_count = primal_count + 1;
     }
+}
+
+// contiguous copy of the RHS column, once at the start of a dual run (single and batched)
+__device__ __forceinline__ void lpx_rhs_init_body(const SelParams& P)
+{
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    for (int i = threadIdx.x; i < R; i += SEL_NT) P.rhsbuf[i] = P.T[(size_t)i * P.ld + (C - 1)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,6 +618,8 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
 
 // single-tableau and batched (blockIdx.y = node of a branch-and-bound group) entry points
 __global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P) { lpx_select_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_rhs_init(SelParams P) { lpx_rhs_init_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_rhs_init_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_rhs_init_body(P); }
 __global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P) { lpx_la_init_body(P); }
 __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P) { lpx_select_mb_body(P); }
 __global__ __launch_bounds__(SEL_NT) void lpx_select_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_select_body(P); }
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_b(const SelParams* __restri
 {
     const SelParams P = arr[blockIdx.y];
     const int ncw = (P.ld + 127) / 128, nunits = ncw * ((P.R + UPD_ROWS - 1) / UPD_ROWS);
-    lpx_update_body(P.T, P.ld, P.R, P.C, P.shape, P.prow, P.pcol, P.pcol, nullptr, P.st, ncw, nunits);
+    lpx_update_body(P.T, P.ld, P.R, P.C, P.shape, P.prow, P.pcol, P.pcol, P.rhsbuf, P.st, ncw, nunits);
 }
 __global__ __launch_bounds__(UPD_NT) void lpx_update_mb_b(const SelParams* __restrict__ arr)
 {
@@ -837,6 +847,16 @@ hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_
 hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s)
 {
     hipLaunchKernelGGL(lpx_la_init_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);
+    return hipGetLastError();
+}
+hipError_t launch_group_rhs_init(const SelParams* arr, int count, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_rhs_init_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);
+    return hipGetLastError();
+}
+hipError_t launch_rhs_init(const SelParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_rhs_init, dim3(1), dim3(SEL_NT), 0, s, p);
     return hipGetLastError();
 }
 int update_blocks(int ld, int R)

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(SEL_NT) void rv_select2(RvParams P)
     const int m = P.m;
     const int iter = st->iter;
     const int q = st->q;
-    const int r = block_hysteresis_segments<SEL_NW>(m, P.tol, RowRatio{P.fac, 1, P.rhsbuf, 1, P.eps});
+    const int r = block_hysteresis_segments<SEL_NW, RowRatio, true>(m, P.tol, RowRatio{P.fac, 1, P.rhsbuf, 1, P.eps});
     if (r < 0) {                                                    // :113-118
         if (t == 0) { st->status = LPX_UNBOUNDED; st->r = -1; }
         return;

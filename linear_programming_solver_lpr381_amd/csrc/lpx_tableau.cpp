@@ -307,7 +307,7 @@ int enqueue_pair(lpx_tableau* t, const SelParams& p, hipStream_t s, hipEvent_t e
 {
     if (p.mode == MODE_DUAL) {
         LPX_HIP_TRY(launch_select(p, s));
-        LPX_HIP_TRY(launch_update(t->T, t->ld, t->Rcap, t->Ccap, t->shape, t->prow, t->pcol, t->pcol, nullptr, t->st, s, e0, e1));
+        LPX_HIP_TRY(launch_update(t->T, t->ld, t->Rcap, t->Ccap, t->shape, t->prow, t->pcol, t->pcol, t->rhsbuf, t->st, s, e0, e1));
     } else if (p.us) {
         LPX_HIP_TRY(launch_select_mb(p, s));
         LPX_HIP_TRY(launch_update_mb(p, s, e0, e1));
@@ -326,6 +326,8 @@ void make_ctx(lpx_tableau* t, const SelParams& p, LoopCtx& c, DevState& init)
     c.enqueue_iter = [t, p](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { return enqueue_pair(t, p, s, e0, e1); };
     if (p.mode != MODE_DUAL)           // lookahead path: first entering column + its gather, once
         c.prologue = [p](hipStream_t s) -> int { LPX_HIP_TRY(launch_la_init(p, s)); return 0; };
+    else                               // dual path: contiguous copy of the RHS column, once
+        c.prologue = [p](hipStream_t s) -> int { LPX_HIP_TRY(launch_rhs_init(p, s)); return 0; };
     c.launches_per_iter = 2;
     c.profile_maps = (p.mode != MODE_DUAL);     // phase hops make the mapping ambiguous in dual mode
     std::memset(&init, 0, sizeof(init));
@@ -671,6 +673,7 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevS
     }
     LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(SelParams) * K, hipMemcpyHostToDevice, g.stream));
     if (!r.dual) LPX_HIP_TRY(launch_group_init(g.d, K, g.stream));
+    else LPX_HIP_TRY(launch_group_rhs_init(g.d, K, g.stream));
     // graph of `batch` iterations, keyed by everything baked into the launches
     char keybuf[160];
     std::snprintf(keybuf, sizeof(keybuf), "%p/%d/%d/%d/%d/%d", (void*)g.d, K, r.dual, r.max_nblk, r.max_blocks, r.batch);
