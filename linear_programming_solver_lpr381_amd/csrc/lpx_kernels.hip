@@ -7,7 +7,7 @@
 // Two launches per pivot on one stream:
 //   lpx_select  (1 workgroup x 1024 lanes)  ChooseEntering + ChooseLeaving + pivot prep
 //   lpx_update  (>> 256 workgroups)         rank-1 update of the whole tableau, HBM-bound
-#include "lpx_block.h"
+#include "lpx_resident.h"      // rs_hysteresis: the hysteresis scan over ratios held in LDS (also pulls in lpx_block.h)
 #include <hip/hip_ext.h>
 
 namespace lpx {
@@ -15,7 +15,22 @@ namespace lpx {
 // ------------------------------------------------------------------------------------------------
 // lpx_select: one workgroup decides the next pivot and prepares the update's operands.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lpx_select_body(const SelParams& P)
+// The two ratio scans of the dual path as real calls: inlined three times (one per phase) their 16-ratio register blocks pushed
+// the 1024-lane kernel (128 VGPRs per lane) into scratch spills -- 13 in lpx_select, 22 in lpx_select_b (code-object metadata).
+__device__ __attribute__((noinline)) int sel_row_scan(int m, double tol, const double* col, size_t cs, const double* rhsb, double eps, int* s_out)
+{
+    return block_hysteresis_auto<SEL_NW>(m, tol, RowRatio{col, cs, rhsb, 1, eps}, s_out);
+}
+__device__ __attribute__((noinline)) int sel_col_scan(int L, double tol, const double* lrow, const double* zrow, double eps, int* s_out)
+{
+    return block_hysteresis_auto<SEL_NW>(L, tol, DualColRatio{lrow, zrow, eps}, s_out);
+}
+
+// `ratios`: dynamic LDS for max(m, C-1) doubles, or nullptr when the tableau is too long for it (then the scans read their
+// operands from global memory on one wave, as in round 1).  With it, ALL 1024 lanes gather the operands and divide in
+// parallel (one round trip, ~1 division per lane), and the chain runs over LDS: minimum + band count on four waves, exact
+// replay on wave 0 only when rows tie (rs_hysteresis, lpx_resident.h -- the scan the resident kernels use, bit-identical).
+__device__ __forceinline__ void lpx_select_body(const SelParams& P, double* ratios)
 {
     __shared__ int s_out;
     __shared__ double s_v[SEL_NW];
@@ -48,7 +63,12 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
                 if (fdf_count >= P.fdf_guard) { phase = 1; continue; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { phase = 1; continue; }
-                r = block_hysteresis_auto<SEL_NW>(m, P.tol_fdf, RowRatio{T + q, ld, rhsb, 1, P.eps}, &s_out);
+                if (ratios) {
+                    for (int i = t; i < m; i += SEL_NT) { const double a = T[(size_t)i * ld + q]; ratios[i] = a > P.eps ? rhsb[i] / a : __builtin_inf(); }
+                    __syncthreads();
+                    r = rs_hysteresis(m, P.tol_fdf, ratios, s_v, s_i, &s_out);
+                } else
+                r = sel_row_scan(m, P.tol_fdf, T + q, ld, rhsb, P.eps, &s_out);
                 if (r < 0) { q = -1; phase = 1; continue; }
             } else if (phase == 1) {
                 // dual loop, Models/DualSimplex.cs:36-113
@@ -61,14 +81,25 @@ __device__ __forceinline__ void lpx_select_body(const SelParams& P)
                     }
                     final_status = LPX_OPTIMAL; break;
                 }
-                q = block_hysteresis_auto<SEL_NW>(rhs, P.tol_dual, DualColRatio{T + (size_t)r * ld, T + (size_t)m * ld, P.eps}, &s_out);
+                if (ratios) {
+                    const double* lrow = T + (size_t)r * ld; const double* zrow = T + (size_t)m * ld;
+                    for (int j = t; j < rhs; j += SEL_NT) { const double a = lrow[j]; ratios[j] = a < -P.eps ? zrow[j] / (-a) : __builtin_inf(); }
+                    __syncthreads();
+                    q = rs_hysteresis(rhs, P.tol_dual, ratios, s_v, s_i, &s_out);
+                } else
+                q = sel_col_scan(rhs, P.tol_dual, T + (size_t)r * ld, T + (size_t)m * ld, P.eps, &s_out);
                 if (q < 0) { r = -1; final_status = LPX_INFEASIBLE; break; }
             } else {
                 // primal loop, Models/PrimalSimplex.cs:92-124
                 if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
                 q = block_first_min_below(T + (size_t)m * ld, 1, rhs, P.eps, s_v, s_i);
                 if (q < 0) { final_status = LPX_OPTIMAL; break; }
-                r = block_hysteresis_auto<SEL_NW>(m, P.tol_primal, RowRatio{T + q, ld, rhsb, 1, P.eps}, &s_out);
+                if (ratios) {
+                    for (int i = t; i < m; i += SEL_NT) { const double a = T[(size_t)i * ld + q]; ratios[i] = a > P.eps ? rhsb[i] / a : __builtin_inf(); }
+                    __syncthreads();
+                    r = rs_hysteresis(m, P.tol_primal, ratios, s_v, s_i, &s_out);
+                } else
+                r = sel_row_scan(m, P.tol_primal, T + q, ld, rhsb, P.eps, &s_out);
                 if (r < 0) { q = -1; final_status = LPX_UNBOUNDED; break; }
             }
         }
@@ -617,12 +648,21 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
 }
 
 // single-tableau and batched (blockIdx.y = node of a branch-and-bound group) entry points
-__global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P) { lpx_select_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_select(SelParams P, int lds_doubles)
+{
+    extern __shared__ __align__(16) double sel_lds[];
+    lpx_select_body(P, lds_doubles > 0 ? sel_lds : nullptr);
+}
 __global__ __launch_bounds__(SEL_NT) void lpx_rhs_init(SelParams P) { lpx_rhs_init_body(P); }
 __global__ __launch_bounds__(SEL_NT) void lpx_rhs_init_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_rhs_init_body(P); }
 __global__ __launch_bounds__(SEL_NT) void lpx_la_init(SelParams P) { lpx_la_init_body(P); }
 __global__ __launch_bounds__(MB_NT) void lpx_select_mb(SelParams P) { lpx_select_mb_body(P); }
-__global__ __launch_bounds__(SEL_NT) void lpx_select_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_select_body(P); }
+__global__ __launch_bounds__(SEL_NT) void lpx_select_b(const SelParams* __restrict__ arr, int lds_doubles)
+{
+    extern __shared__ __align__(16) double sel_lds[];
+    const SelParams P = arr[blockIdx.y];
+    lpx_select_body(P, lds_doubles > 0 ? sel_lds : nullptr);
+}
 __global__ __launch_bounds__(SEL_NT) void lpx_la_init_b(const SelParams* __restrict__ arr) { const SelParams P = arr[blockIdx.y]; lpx_la_init_body(P); }
 __global__ __launch_bounds__(MB_NT) void lpx_select_mb_b(const SelParams* __restrict__ arr)
 {
@@ -770,11 +810,26 @@ hipError_t debug_copy_stamps(unsigned long long* out, int clear)
 }
 #endif
 
-hipError_t kernels_init() { return hipSuccess; }
+static constexpr int SEL_LDS_MAX_DOUBLES = 16 * 1024;          // 128 KB of ratios: tableaux up to 16k rows / columns
+
+hipError_t kernels_init()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SEL_LDS_MAX_DOUBLES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_select_b), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SEL_LDS_MAX_DOUBLES);
+    return e;
+}
+
+// doubles of dynamic LDS the dual select needs for a tableau of capacity R x C (0 = too long, scan from global memory)
+static int select_lds_doubles(int R, int C)
+{
+    const int L = ((R > C ? R : C) + 1) & ~1;
+    return L <= SEL_LDS_MAX_DOUBLES ? L : 0;
+}
 
 hipError_t launch_select(const SelParams& p, hipStream_t s)
 {
-    hipLaunchKernelGGL(lpx_select, dim3(1), dim3(SEL_NT), 0, s, p);
+    const int L = select_lds_doubles(p.R, p.C);
+    hipLaunchKernelGGL(lpx_select, dim3(1), dim3(SEL_NT), sizeof(double) * L, s, p, L);
     return hipGetLastError();
 }
 
@@ -833,10 +888,11 @@ hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hi
 }
 
 // one iteration of a whole group: `arr` holds `count` parameter records in device memory
-hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s)
+hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s, int maxR, int maxC)
 {
     if (dual) {
-        hipLaunchKernelGGL(lpx_select_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);
+        const int L = select_lds_doubles(maxR, maxC);
+        hipLaunchKernelGGL(lpx_select_b, dim3(1, count), dim3(SEL_NT), sizeof(double) * L, s, arr, L);
         hipLaunchKernelGGL(lpx_update_b, dim3(max_upd_blocks, count), dim3(UPD_NT), 0, s, arr);
     } else {
         hipLaunchKernelGGL(lpx_select_mb_b, dim3(max_nblk, count), dim3(MB_NT), 0, s, arr);

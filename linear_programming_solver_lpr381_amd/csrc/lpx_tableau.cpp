@@ -641,7 +641,7 @@ int group_reserve(GroupBuf& g, int count)
 
 struct GroupRun {
     GroupBuf* g = nullptr; std::vector<int> idx; int dual = 0; int batch = 64; long long budget = 0, enq = 0;
-    int max_nblk = 1, max_blocks = 1; bool done = true;
+    int max_nblk = 1, max_blocks = 1, maxR = 2, maxC = 2; bool done = true;
 };
 
 int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevState* inits = nullptr)
@@ -651,7 +651,7 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevS
     int rc = group_reserve(g, K); if (rc) return rc;
     r.batch = o->batch > 0 ? o->batch : 64;
     r.budget = r.dual ? (long long)o->fdf_guard + 2LL * o->max_iter + 8 : (long long)o->max_iter + 2;
-    r.max_nblk = 1; r.max_blocks = 1;
+    r.max_nblk = 1; r.max_blocks = 1; r.maxR = 2; r.maxC = 2;
     for (int k = 0; k < K; ++k) {
         lpx_tableau* t = ts[r.idx[k]];
         LPX_HIP_TRY(hipStreamSynchronize(t->stream));               // node assembly ran on the node's own stream
@@ -661,6 +661,8 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevS
         if (p.nblk > r.max_nblk) r.max_nblk = p.nblk;
         const int ub = update_blocks(t->ld, t->Rcap);
         if (ub > r.max_blocks) r.max_blocks = ub;
+        if (t->Rcap > r.maxR) r.maxR = t->Rcap;
+        if (t->Ccap > r.maxC) r.maxC = t->Ccap;
         DevState init; std::memset(&init, 0, sizeof(init));
         init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = r.dual ? 0 : 2;
         if (inits) {                                // continue where another path stopped (pivot count, phase, counters)
@@ -676,14 +678,14 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevS
     else LPX_HIP_TRY(launch_group_rhs_init(g.d, K, g.stream));
     // graph of `batch` iterations, keyed by everything baked into the launches
     char keybuf[160];
-    std::snprintf(keybuf, sizeof(keybuf), "%p/%d/%d/%d/%d/%d", (void*)g.d, K, r.dual, r.max_nblk, r.max_blocks, r.batch);
+    std::snprintf(keybuf, sizeof(keybuf), "%p/%d/%d/%d/%d/%d/%d/%d", (void*)g.d, K, r.dual, r.max_nblk, r.max_blocks, r.batch, r.maxR, r.maxC);
     if (o->use_graph && g.gkey != keybuf) {
         if (g.gexec) { hipGraphExecDestroy(g.gexec); g.gexec = nullptr; }
         LPX_HIP_TRY(hipStreamSynchronize(g.stream));
         hipGraph_t graph = nullptr;
         LPX_HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < r.batch; ++i) {
-            hipError_t e = launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream);
+            hipError_t e = launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream, r.maxR, r.maxC);
             if (e != hipSuccess) { hipStreamEndCapture(g.stream, &graph); if (graph) hipGraphDestroy(graph); set_error("group capture failed"); return LPX_EDEVICE; }
         }
         LPX_HIP_TRY(hipStreamEndCapture(g.stream, &graph));
@@ -701,7 +703,7 @@ int group_submit(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
     GroupBuf& g = *r.g;
     const int K = (int)r.idx.size();
     if (o->use_graph && g.gexec) LPX_HIP_TRY(hipGraphLaunch(g.gexec, g.stream));
-    else for (int i = 0; i < r.batch; ++i) LPX_HIP_TRY(launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream));
+    else for (int i = 0; i < r.batch; ++i) LPX_HIP_TRY(launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream, r.maxR, r.maxC));
     r.enq += r.batch;
     for (int k = 0; k < K; ++k)
         LPX_HIP_TRY(hipMemcpyAsync(&g.hs[k], ts[r.idx[k]]->st, sizeof(DevState), hipMemcpyDeviceToHost, g.stream));
