@@ -227,3 +227,38 @@ def test_drift_policy_checks_the_residual_and_refactors_only_when_asked(gpu, ora
     assert tr.tolist() == ref.trace.tolist() == tr0[:10].tolist()
     assert Bidx1.tolist() == ref.Bidx.tolist() and Nidx1.tolist() == ref.Nidx.tolist()
     assert abs(z1 - ref.z_internal) <= REL * abs(ref.z_internal)
+
+
+def test_five_launch_path_still_matches_the_oracle(oracle):
+    """LPX_REVISED_FUSED=0: the round-1 iteration (separate pricing / pick / FTRAN / select / eager W update), which is also
+    the path of bases with more than 8192 rows -- same pivots, Bidx, Nidx as the oracle and as the fused path."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, json
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        out = []
+        for (m, n, seed) in [(20, 30, 7), (96, 160, 9), (257, 300, 5)]:
+            c, A, b = synth.dense_lp(m, n, seed=seed)
+            with L.DeviceRevised(A, -c, b) as rv:
+                status, st = rv.run()
+                Bidx, Nidx, xB, z = rv.result()
+                out.append([status, rv.trace().tolist(), Bidx.tolist(), Nidx.tolist(), z])
+        print(json.dumps(out))
+    ''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fused in ("1", "0"):
+        env = dict(os.environ, LPX_REVISED_FUSED=fused, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        import json
+        res[fused] = json.loads(r.stdout.strip().splitlines()[-1])
+    for k, (m, n, seed) in enumerate([(20, 30, 7), (96, 160, 9), (257, 300, 5)]):
+        c, A, b = synth.dense_lp(m, n, seed=seed)
+        ref = oracle.revised_solve(oracle.Problem(oracle.MAX, c, A, np.zeros(m, np.int32), b))
+        for fused in ("1", "0"):
+            status, tr, Bidx, Nidx, z = res[fused][k]
+            assert status == ref.status == 0 and tr == ref.trace.tolist(), (fused, m)
+            assert Bidx == ref.Bidx.tolist() and Nidx == ref.Nidx.tolist()
+            assert abs(z - ref.z_internal) <= REL * abs(ref.z_internal)
