@@ -416,7 +416,12 @@ def main():
                                             "peak": 78.6, "unit": "TFLOP/s", "frac": gemm_tf / 78.6 if gemm_tf else None,
                                             "gemm_calls": fst["gemm_calls"], "gemm_ms": fst["gemm_ms"],
                                             "flops_per_call": 2.0 * 4096 ** 3, "newton_schulz_steps": fst["fast_steps"],
-                                            "peak_source": "MI355X FP64 matrix = vector peak 78.6 TFLOP/s (SURVEY 8d; 32 flop/clk/SIMD)"},
+                                            "peak_source": "MI355X FP64 matrix = vector peak 78.6 TFLOP/s (SURVEY 8d; 32 flop/clk/SIMD)",
+                                            "measured_mfma_issue_rate_tflops": 36.2,
+                                            "measured_mfma_issue_rate_source": "profiles/r02_kbench_mfma_f64_rate.txt: v_mfma_f64_16x16x4_f64 back to back, "
+                                                                               "16 independent accumulators, one wave per SIMD, every CU (tools/kbench/mfma_f64_rate.hip) "
+                                                                               "-- a committed microbenchmark, not a measurement of this run",
+                                            "frac_vs_measured_issue_rate": gemm_tf / 36.2 if gemm_tf else None},
                           "refactor_note": "exact = the reference's Invert (4096 Gauss-Jordan steps x 16*m*2m bytes), which the reference runs "
                                            "EVERY iteration; fast = one Newton-Schulz step from the maintained inverse; the engine runs either on demand"}
         rv.close()

@@ -8,8 +8,8 @@
 //
 // does that with two dense m x m x m contractions -- the "dense panel contraction" for which north_star admits MFMA.
 // They run on v_mfma_f64_16x16x4_f64: block tile 128 x 128, K-step 16, four waves of 64 x 64 (4 x 4 MFMA tiles, 128
-// accumulator VGPRs per lane), operands staged through LDS with the next K-step's global loads in flight during the
-// MFMAs.  An FP64 16x16x4 MFMA keeps a SIMD busy for 64 cycles (32 flop / clk / SIMD, the FP64 vector rate: 78.6 TFLOP/s
+// accumulator VGPRs per lane), operands staged through double-buffered LDS (one barrier per K-step) with the next K-step's
+// global loads in flight during the MFMAs.  An FP64 16x16x4 MFMA keeps a SIMD busy for 64 cycles (32 flop / clk / SIMD, the FP64 vector rate: 78.6 TFLOP/s
 // on the chip), so LDS and L2 traffic stay far below their limits and the loop is matrix-pipe bound.
 // The exact, bit-faithful Gauss-Jordan (inv_select + lpx_update in lpx_revised.hip) stays the parity mode and the
 // fallback when R is not small.  Rounding of this path differs from the reference's Invert (FMA accumulation): it is
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(GM_NT) void dgemm_mfma_f64(const double* __restrict
                                                         double* __restrict__ C, int ldc, const double* __restrict__ D, int ldd,
                                                         int M, int N, int K, int mode, unsigned long long* absmax)
 {
-    __shared__ __align__(16) double As[GM_BM * GM_LDA];
-    __shared__ __align__(16) double Bs[GM_BK * GM_LDB];
+    __shared__ __align__(16) double As2[2][GM_BM * GM_LDA];      // double buffered: one barrier per K-step
+    __shared__ __align__(16) double Bs2[2][GM_BK * GM_LDB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;                   // 2 x 2 waves, 64 x 64 each
     const int bm = blockIdx.y * GM_BM, bn = blockIdx.x * GM_BN;
@@ -60,11 +60,11 @@ __global__ __launch_bounds__(GM_NT) void dgemm_mfma_f64(const double* __restrict
             rb[u] = v;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<mf_d2*>(&As[ar * GM_LDA + ak + 2 * u]) = ra[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<mf_d2*>(&As2[buf][ar * GM_LDA + ak + 2 * u]) = ra[u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<mf_d2*>(&Bs[br * GM_LDB + bc + 2 * u]) = rb[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<mf_d2*>(&Bs2[buf][br * GM_LDB + bc + 2 * u]) = rb[u];
     };
     mf_d4 acc[4][4];
 #pragma unroll
@@ -74,11 +74,13 @@ __global__ __launch_bounds__(GM_NT) void dgemm_mfma_f64(const double* __restrict
 
     const int KT = (K + GM_BK - 1) / GM_BK;
     gload(0);
-    lstore();
+    lstore(0);
     __syncthreads();
     const int lr = lane & 15, lk = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) gload((kt + 1) * GM_BK);               // in flight while the matrix pipe works
+        const double* As = As2[kt & 1];
+        const double* Bs = Bs2[kt & 1];
 #pragma unroll
         for (int kk = 0; kk < GM_BK; kk += 4) {
             double a[4], b[4];
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(GM_NT) void dgemm_mfma_f64(const double* __restrict
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < KT) lstore((kt + 1) & 1);                  // the other buffer: nobody reads it during this step
         __syncthreads();
-        if (kt + 1 < KT) { lstore(); __syncthreads(); }
     }
     // epilogue: C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
     double mx = 0.0;
