@@ -115,7 +115,8 @@ __global__ __launch_bounds__(RV_NT) void rv_price_pick(RvParams P)
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (st->iter >= P.max_iter) {                       // :66 / :144
+    if (st->iter >= st->dual_iter) {                    // :66 / :144 -- the cap travels in the state record (DevState::dual_iter is
+                                                        //   unused by this path), so the captured graph serves every segment of a run
         if (t == 0) { st->status = LPX_ITER_LIMIT; st->r = -1; }
         return;
     }
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(RV_NT) void rv_pick(RvParams P)
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (st->iter >= P.max_iter) {                       // :66 / :144
+    if (st->iter >= st->dual_iter) {                    // :66 / :144 -- the cap travels in the state record (DevState::dual_iter is
+                                                        //   unused by this path), so the captured graph serves every segment of a run
         if (t == 0) { st->status = LPX_ITER_LIMIT; st->r = -1; }
         return;
     }
@@ -761,7 +763,7 @@ static RvParams rv_params(lpx_revised* r, const lpx_run_opts* o)
     p.m = r->m; p.n = r->n; p.ldat = r->ldat; p.ldw = r->ldw;
     p.AT = r->AT; p.c = r->c; p.W = r->W; p.prow = r->prow; p.fac = r->fac; p.rhsbuf = r->rhsbuf;
     p.rc = r->rc; p.aq = r->aq; p.Bidx = r->Bidx; p.key = r->key; p.trace = r->trace; p.trace_cap = r->trace_cap;
-    p.st = r->st; p.eps = o->eps; p.tol = o->ratio_tol; p.max_iter = o->max_iter;
+    p.st = r->st; p.eps = o->eps; p.tol = o->ratio_tol; p.max_iter = 0;       // the iteration cap is DevState::dual_iter
     p.ws = r->ws; p.rcap = 0;
     p.part_v = r->part_v; p.part_k = r->part_k; p.part_c = r->part_c;
     p.nblk = std::min(RVF_GRID, std::max((r->n + 1) / 2, (r->m + RVF_NT - 1) / RVF_NT));
@@ -1108,6 +1110,7 @@ static int revised_run_segment(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
     init.iter = iter0;             // continuing after a refactorisation keeps the iteration count and the trace
+    init.dual_iter = o->max_iter;  // iteration cap of this segment, read by rv_pick / rv_price_pick
     // continue from the handle's current basis: the order-key counter lives in pad[0]
     LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
     init.pad[0] = r->hst->pad[0] > 0 ? r->hst->pad[0] : r->n;
