@@ -183,3 +183,26 @@ def test_config5_root_bound_and_order(gpu, oracle):
         if rf >= 0:
             assert X[j] == rx[order[rf]]
     dk.close()
+
+
+def test_dual_path_on_a_tableau_larger_than_the_infinity_cache(gpu, oracle):
+    """lpx_update_s (the streaming variant of the dual / forced path's update kernel: 3 rows per wave, non-temporal loads and
+    stores) only runs above 320 MiB: a 4501 x 10001 dual tableau (361 MB), first pivots of ForceDualFeasibility + dual loop +
+    clean-up, bit-equal to the oracle."""
+    m, n = 4500, 5500
+    c, A, b = synth.dense_lp(m, n, seed=11)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    del A
+    g = np.random.Generator(np.random.PCG64(11))
+    for i in g.choice(m, size=12, replace=False):
+        T[i, :n] *= -1.0
+        T[i, -1] = -0.02 * T[i, -1]
+    assert T.nbytes > (320 << 20)
+    Tr, br = T.copy(), basis.copy()
+    st_ref, tr_ref, nf = oracle.dual_tableau(Tr, br, fdf_guard=4, cleanup=1, max_iter=6)
+    with gpu.DeviceTableau.from_host(T, basis) as dt:
+        status, st = dt.dual_run(fdf_guard=4, cleanup=1, max_iter=6)
+        tr = dt.trace()
+        Tg, bg = dt.download()
+    assert status == st_ref and tr.tolist() == tr_ref.tolist() and len(tr) >= 6 and st["fdf_pivots"] == nf
+    assert bg.tolist() == br.tolist() and np.array_equal(_bits(Tg), _bits(Tr))
