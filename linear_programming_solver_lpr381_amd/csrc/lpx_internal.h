@@ -102,6 +102,16 @@ hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int
                                   unsigned long long* xr, unsigned long long* xp, unsigned* xgen,
                                   double eps, double tol, int max_iter, int chunk, hipStream_t s);
 
+// resident primal loop with column-owning workgroups (lpx_resident_col.hip): one exchange per pivot
+hipError_t resident_col_init();
+int resident_col_plan(int R, int C, int* grid, int* cpw, size_t* lds);          // 0 = does not fit on chip
+size_t resident_col_xc_bytes(int grid);
+size_t resident_col_xq_bytes(int grid, int R);
+hipError_t launch_resident_primal_col(double* T, int ld, int R, int C, int grid, int cpw, size_t lds,
+                                      int32_t* basis, int32_t* trace, int trace_cap, DevState* st,
+                                      unsigned long long* xc, unsigned long long* xq, unsigned* xgen,
+                                      double eps, double tol, int max_iter, int chunk, hipStream_t s);
+
 void set_error(const std::string& msg);
 int ensure_device();                // binds a device and sets kernel attributes once
 double now_ms();

@@ -70,6 +70,14 @@ __device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
     return false;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it waits for
+// the acknowledgements of the write-through (sc1) granule stores a workgroup has just published -- 1.5-2 us that nobody in the
+// workgroup needs: the granules are consumed by OTHER workgroups, which validate them by their tags.
+__device__ __forceinline__ void rs_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Abort flag of a resident launch (DevState::pad[1]), read past the L1 (sc1) like every other cross-workgroup word.
 __device__ __forceinline__ int rs_abort_raised(const DevState* st)
 {

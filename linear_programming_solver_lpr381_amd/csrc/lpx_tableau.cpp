@@ -46,6 +46,8 @@ struct lpx_tableau {
     unsigned long long* xr = nullptr; unsigned long long* xp = nullptr; unsigned* xgen = nullptr;
     int32_t* xbasis = nullptr;      // basis as it was when the current resident launch started
     double* xT = nullptr;           // tableau as it was when the current resident launch started (put back if the launch aborts)
+    unsigned long long* xc = nullptr; unsigned long long* xq = nullptr;   // column-owning resident kernel: candidates / candidate columns
+    size_t xc_bytes = 0, xq_bytes = 0;
     bool resident_off = false;      // a resident launch could not get its workgroups co-resident: stay on the streaming path
 };
 
@@ -179,7 +181,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     for (hipEvent_t e : t->events) hipEventDestroy(e);
     hipFree(t->T); hipFree(t->slab); hipFree(t->snapT); hipFree(t->snapBasis);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf);
-    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis); hipFree(t->xT);
+    hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis); hipFree(t->xT); hipFree(t->xc); hipFree(t->xq);
     if (t->hslab) hipHostFree(t->hslab);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
     delete t;                       // the stream is borrowed (borrow_stream), not owned
@@ -254,6 +256,13 @@ int lpx_tableau_device_ptr(lpx_tableau* t, void** dptr, int* ld)
 }
 
 #ifdef LPX_STAMPS
+int lpx_debug_resident_col(lpx_tableau* t, unsigned long long* out, int n, int clear)
+{
+    if (!t->xc) return LPX_EINVAL;
+    LPX_HIP_TRY(hipMemcpy(out, t->xc + 2 * 256 * 2 * 2, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (clear) LPX_HIP_TRY(hipMemset(t->xc + 2 * 256 * 2 * 2, 0, sizeof(unsigned long long) * n));
+    return 0;
+}
 int lpx_debug_resident_group(lpx_tableau* t, unsigned long long* out, int n, int clear)
 {
     if (!t->xp) return LPX_EINVAL;
@@ -379,8 +388,22 @@ static int resident_buffers(lpx_tableau* t)
     LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
     return 0;
 }
+// exchange buffers of the column-owning kernel, sized for the handle's capacity and every grid up to the CU count
+static int resident_col_buffers(lpx_tableau* t, int grid)
+{
+    const size_t xcb = resident_col_xc_bytes(grid > 256 ? grid : 256), xqb = resident_col_xq_bytes(grid > 256 ? grid : 256, t->Rcap);
+    if (t->xc && t->xc_bytes >= xcb && t->xq_bytes >= xqb) return 0;
+    hipFree(t->xc); hipFree(t->xq); t->xc = nullptr; t->xq = nullptr;
+    LPX_HIP_TRY(hipMalloc((void**)&t->xc, xcb));
+    LPX_HIP_TRY(hipMalloc((void**)&t->xq, xqb));
+    t->xc_bytes = xcb; t->xq_bytes = xqb;
+    LPX_HIP_TRY(hipMemsetAsync(t->xc, 0, xcb, t->stream));
+    LPX_HIP_TRY(hipMemsetAsync(t->xq, 0, xqb, t->stream));
+    return 0;
+}
 static void resident_buffers_clear(lpx_tableau* t)
 {
+    if (t->xc) { hipMemsetAsync(t->xc, 0, t->xc_bytes, t->stream); hipMemsetAsync(t->xq, 0, t->xq_bytes, t->stream); }
     hipMemsetAsync(t->xr, 0, xr_bytes(t), t->stream);
     hipMemsetAsync(t->xp, 0, xp_bytes(t), t->stream);
     hipStreamSynchronize(t->stream);
@@ -388,11 +411,13 @@ static void resident_buffers_clear(lpx_tableau* t)
 
 // Resident primal loop: one launch runs up to `chunk` pivots with the tableau in LDS; the host only polls the
 // 64-byte state record between launches (and fires the pivot callbacks from the trace).
+// col: the column-owning kernel (lpx_resident_col.hip; grid / cpw / lds from resident_col_plan), else the row-owning one
 int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* user, lpx_stats* stats,
-                 int grid, int rpw, size_t lds, int* resume_iter)
+                 int grid, int rpw, size_t lds, int* resume_iter, bool col = false)
 {
     const int mcap = t->Rcap;
     { int rc = resident_buffers(t); if (rc) return rc; }
+    if (col) { int rc = resident_col_buffers(t, grid); if (rc) return rc; }
     DevState init; std::memset(&init, 0, sizeof(init));
     init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2;
     *t->hst = init;
@@ -412,6 +437,10 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
             while (t->events.size() < 2) { hipEvent_t e; LPX_HIP_TRY(hipEventCreate(&e)); t->events.push_back(e); }
             LPX_HIP_TRY(hipEventRecord(t->events[0], t->stream));
         }
+        if (col)
+            LPX_HIP_TRY(launch_resident_primal_col(t->T, t->ld, t->R, t->C, grid, rpw, lds, t->basis, t->trace, t->trace_cap,
+                                                   t->st, t->xc, t->xq, t->xgen, o->eps, o->ratio_tol, o->max_iter, chunk, t->stream));
+        else
         LPX_HIP_TRY(launch_resident_primal(t->T, t->ld, t->R, t->C, grid, rpw, lds, mcap, t->basis, t->trace, t->trace_cap,
                                            t->st, t->xr, t->xp, t->xgen, o->eps, o->ratio_tol, o->max_iter, chunk, t->stream));
         if (o->profile) LPX_HIP_TRY(hipEventRecord(t->events[1], t->stream));
@@ -768,8 +797,14 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
     int resume = 0;
     if (o->resident > 0 || (o->resident == 0 && res_env && !o->profile && (o->batch == 0 || o->batch >= 32))) {
         int grid = 0, rpw = 0; size_t lds = 0;
-        if (!t->resident_off && resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds)) {
-            const int rc = run_resident(t, o, cb, user, st, grid, rpw, lds, &resume);
+        // LPX_RESIDENT_COL=1: the column-owning variant (lpx_resident_col.hip) when a workgroup's columns fit its LDS.  It was
+        // built to save one of the two cross-CU exchanges per pivot and is bit-identical, but measures the same 7.9-8.0 us per
+        // pivot on config 2 as the row-owning kernel, so the row-owning one -- which fits more shapes -- stays the default.
+        static const bool col_env = [] { const char* e = std::getenv("LPX_RESIDENT_COL"); return e && e[0] == '1'; }();
+        bool col = false;
+        if (!t->resident_off && col_env && resident_col_plan(t->R, t->C, &grid, &rpw, &lds)) col = true;
+        if (!t->resident_off && (col || resident_plan(t->R, t->C, t->ld, &grid, &rpw, &lds))) {
+            const int rc = run_resident(t, o, cb, user, st, grid, rpw, lds, &resume, col);
             if (rc != LPX_RESIDENT_RETRY) return rc;
             if (o->resident > 0) return LPX_EDEVICE;        // required, and it could not run
         } else

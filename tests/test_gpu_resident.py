@@ -338,3 +338,54 @@ def test_late_workgroup_cannot_leave_a_half_pivoted_tableau(oracle):
     env = dict(os.environ, LPX_RESIDENT_TEST_MUTE="3", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_column_owning_resident_kernel_is_bit_identical(oracle):
+    """LPX_RESIDENT_COL=1: lpx_resident_primal_col (workgroups own columns, candidates + candidate columns in one exchange)
+    gives the oracle's bits on ragged shapes, ties, every terminal status, chunked callbacks and config 2 in full."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, hashlib
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        from oracle import oracle as O
+        def bits(a): return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+        for (m, n, seed) in [(1, 1, 1), (3, 5, 2), (40, 64, 3), (257, 769, 4), (513, 1100, 5), (300, 7, 6), (1024, 2048, synth.SEED)]:
+            c, A, b = synth.dense_lp(m, n, seed=seed)
+            T, basis = synth.primal_tableau_from(c, A, b)
+            Tr, br = T.copy(), basis.copy()
+            st, tr = O.primal_tableau(Tr, br)
+            ev = []
+            with L.DeviceTableau.from_host(T, basis) as dt:
+                status, s1 = dt.primal_run(L.default_opts(False, resident=1, batch=37 if m < 300 else 0),
+                                           cb=(lambda it, r, q: ev.append((r, q))) if m < 300 else None)
+                Tg, bg = dt.download()
+                assert status == st and s1["pivots"] == len(tr), (m, n)
+                assert dt.trace().tolist() == tr.tolist() and bg.tolist() == br.tolist()
+                assert np.array_equal(bits(Tg), bits(Tr)), (m, n)
+                if m < 300: assert [list(e) for e in ev] == tr.tolist()
+        # degenerate ties and an unbounded column
+        g = np.random.default_rng(5)
+        A = g.integers(0, 3, size=(700, 9)).astype(float); b = g.integers(0, 2, size=700).astype(float)
+        c = g.integers(1, 9, size=9).astype(float)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy(); st, tr = O.primal_tableau(Tr, br)
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, _ = dt.primal_run(resident=1); Tg, bg = dt.download()
+            assert status == st and dt.trace().tolist() == tr.tolist() and np.array_equal(bits(Tg), bits(Tr))
+        T = np.array([[-1.0, 1.0, 1.0, 0.0, 1.0], [-2.0, 0.5, 0.0, 1.0, 3.0], [-1.0, -1.0, 0.0, 0.0, 0.0]]); basis = np.array([2, 3], np.int32)
+        Tr, br = T.copy(), basis.copy(); st, tr = O.primal_tableau(Tr, br)
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, _ = dt.primal_run(resident=1)
+            assert status == st == 1 and dt.trace().tolist() == tr.tolist()
+        # iteration limit in the middle of a launch
+        c, A, b = synth.dense_lp(64, 100, seed=9); T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy(); st, tr = O.primal_tableau(Tr, br, max_iter=11)
+        with L.DeviceTableau.from_host(T, basis) as dt:
+            status, _ = dt.primal_run(resident=1, max_iter=11); Tg, bg = dt.download()
+            assert status == st == 3 and dt.trace().tolist() == tr.tolist() and np.array_equal(bits(Tg), bits(Tr))
+        print("OK")
+    ''')
+    env = dict(os.environ, LPX_RESIDENT_COL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
