@@ -28,3 +28,9 @@ dt = L.DeviceTableau.from_host(T, basis)
 status, st = dt.primal_run(use_graph=0, batch=20, max_iter=npiv)
 print("lp-level pivots", st["pivots"], "status", status)
 dt.close()
+# config 3: the fused revised iteration (rv_price streams A^T with nt loads, rv_upd_ftran reads + writes W once)
+c3, A3, b3 = synth.dense_lp(4096, 8192)
+rv = L.DeviceRevised(A3, -c3, b3)
+status, st = rv.run(max_iter=npiv, batch=20, use_graph=0)
+print("revised iterations", st["pivots"], "status", status)
+rv.close()
