@@ -15,6 +15,7 @@
 #include "model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -53,17 +54,20 @@ struct KNode {
 using NodeP = std::unique_ptr<KNode>;
 
 struct Heap {                                              // SimpleMaxHeap<Node>, :494-547
-    std::vector<KNode*> d;
-    static int cmp(const KNode* a, const KNode* b) { return (a->bound > b->bound) - (a->bound < b->bound); }
+    // the key sits beside the pointer: a sift compares array entries only (the reference compares node.Bound through the
+    // reference, same values) -- with 10^5..10^6 nodes the pointer chase was most of the host time per pop
+    struct E { double bound; KNode* n; };
+    std::vector<E> d;
+    static int cmp(const E& a, const E& b) { return (a.bound > b.bound) - (a.bound < b.bound); }
     void push(KNode* x) {
-        d.push_back(x);
+        d.push_back(E{x->bound, x});
         size_t ci = d.size() - 1;
         while (ci > 0) { size_t pi = (ci - 1) / 2; if (cmp(d[ci], d[pi]) <= 0) break; std::swap(d[ci], d[pi]); ci = pi; }
     }
     KNode* pop() {
         size_t li = d.size() - 1;
         std::swap(d[0], d[li]);
-        KNode* ret = d[li]; d.pop_back();
+        KNode* ret = d[li].n; d.pop_back();
         if (d.empty()) return ret;
         li = d.size() - 1;
         size_t i = 0;
@@ -84,6 +88,7 @@ struct Search {
     double best = -INFINITY; std::vector<int32_t> bestX; bool has_best = false;
     int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0;
     int64_t redundant_popped = 0, redundant_relax = 0;   // replicated warm-up on ranks != 0
+    double dev_ms = 0;                                   // wall time inside the lpx_knapsack_* calls (launch + wait)
     int spec = 64;
     std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
 
@@ -94,13 +99,18 @@ struct Search {
     void run_jobs(std::vector<Job>& jobs)
     {
         if (jobs.empty()) return;
+        struct Clock { double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); bool on = false;
+                       void start() { t0 = std::chrono::steady_clock::now(); on = true; }
+                       void stop() { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); on = false; } } clk{dev_ms};
         const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
         std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
         if (use_store && jobs[0].item >= 0) {
             // 32 bytes per job: (parent id, item, value); the device derives, stores and evaluates the child
             std::vector<int64_t> par(jobs.size()), ch(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
             for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = jobs[j].item; vv[j] = (int8_t)jobs[j].v; }
+            clk.start();
             int rc = lpx_knapsack_expand_batch(k, (int)jobs.size(), par.data(), it.data(), vv.data(), ch.data(), p.data(), w.data(), fr.data(), fv.data());
+            clk.stop();
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
             for (size_t j = 0; j < jobs.size(); ++j) {
                 KNode* nd = jobs[j].node; const int v = jobs[j].v;
@@ -120,9 +130,11 @@ struct Search {
                 off[j + 1] = (int32_t)fidx.size();
             }
             if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
+            clk.start();
             int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
                    : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
                             : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
+            clk.stop();
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
         }
         ++launches;
@@ -219,7 +231,7 @@ struct Search {
             jobs.push_back({node, item, 1, &node->child[1], node->gchild[1]});
             const size_t lim = std::min<size_t>(pq.d.size(), (size_t)spec);
             for (size_t i = 0; i < lim; ++i) {
-                KNode* o = pq.d[i];
+                KNode* o = pq.d[i].n;
                 if (o->child[0].valid || o->self.frac < 0 || o->bound <= best + EPS) continue;
                 const int it = order[o->self.frac];
                 jobs.push_back({o, it, 0, &o->child[0], o->gchild[0]});
@@ -293,7 +305,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     for (;;) {
         if (replicated && pq.d.size() >= (size_t)(4 * world)) {
             Heap mine;
-            for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i]);
+            for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i].n);
             pq.d.swap(mine.d);
             replicated = false;
             if (rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }   // rank 0 accounts for the warm-up
@@ -350,6 +362,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     res.Nodes = S.popped - S.redundant_popped; res.LpSolves = S.relaxations - S.redundant_relax;
     res.NodeZ = {(double)(S.relaxations - S.redundant_relax), (double)(S.popped - S.redundant_popped), (double)S.expanded, (double)S.max_heap};
     res.Stats.launches = S.launches;
+    res.Stats.loop_ms = S.dev_ms;                                           // time inside the device calls; the rest of the wall time is the host replay
     return res;
 }
 

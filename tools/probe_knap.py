@@ -9,4 +9,4 @@ pk, wk, capk = synth.knapsack(100_000)
 kp = L.LPProblem(L.Sense.Max, pk.tolist(), [L.Constraint(wk.tolist(), L.Rel.LE, capk)])
 for conc in (64, 512, 512):
     t0 = time.perf_counter(); r = L.BranchAndBoundKnapsack(max_nodes=200000, concurrent_nodes=conc).Solve(kp); dt = time.perf_counter() - t0
-    print(f"conc={conc}: 200k pops {dt:.3f} s, {r.Nodes/dt:.0f} nodes/s, launches {r.Stats['launches']}, {1e6*dt/max(r.Stats['launches'],1):.1f} us per launch, z {r.OptimalValue}", flush=True)
+    print(f"conc={conc}: 200k pops {dt:.3f} s, {r.Nodes/dt:.0f} nodes/s, launches {r.Stats['launches']}, {1e6*dt/max(r.Stats['launches'],1):.1f} us per launch, device calls {r.Stats['loop_ms']:.1f} ms of {1e3*dt:.1f}, z {r.OptimalValue}", flush=True)
