@@ -3,10 +3,16 @@
 // The search is the reference's: best-first on the greedy fractional bound with its own array heap
 // (Push sift-up breaks on `<= 0`, Pop swaps the last element in and sifts down, :494-547), left child
 // (x=0) evaluated before right child (x=1), incumbent rule `> best + 1e-9`.  What moves to the GPU is
-// ComputeRelaxation: the children of the node being expanded AND of the next `spec` nodes near the top
-// of the heap are evaluated in ONE lpx_knapsack_relax_batch launch and cached on the nodes, so the
-// host replays the exact reference order while the device sees batches.  A relaxation depends only on
-// the node's fixed set, never on the search order, so caching cannot change any decision.
+// ComputeRelaxation -- in bulk and AHEAD of the search:
+//   * every relaxation the device has produced is a node of an "evaluated tree" (KNode: parent + one decision + its
+//     bound); the reference's heap holds pointers into that tree, so pushing a child allocates and computes nothing;
+//   * the evaluated leaves (bound known, children not) sit in a second max-heap keyed by the same bound the search pops
+//     by.  Best-first pops in bound order, so the leaves with the largest bounds ARE the nodes whose children the search
+//     asks for next: whenever the loop reaches a node whose children are missing, one launch evaluates that node and
+//     the `spec` best leaves (each job: a child and that child's two children, lpx_knapsack_expand_batch);
+//   * a relaxation depends only on the node's fixed set, never on the search order, so evaluating early cannot change
+//     any decision: the host replays the exact reference order (popped / expanded / relaxations counts equal the CPU
+//     restatement's) while the device sees batches of hundreds of jobs instead of one node at a time.
 // Report text (3n lines per expansion, :139-143) is not produced.
 //
 // Sharded form (world > 1): the tree is expanded redundantly until the heap holds >= 4*world nodes,
@@ -19,6 +25,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
 
@@ -35,13 +42,12 @@ struct Relax { double profit = 0, weight = 0, fracval = 0; int frac = -1; bool v
 struct KNode {
     // a node is its parent plus one decision (:207-209, :267-269); the fixed list itself lives in the device store
     // (lpx_knapsack_expand_batch) under `dev`, or is rebuilt from this chain when a host-side list is needed
-    KNode* parent = nullptr; int32_t item = -1; int8_t val = 0; int32_t depth = 0;
+    KNode* parent = nullptr;
+    KNode* kid[2] = {nullptr, nullptr};                    // evaluated children (x=0, x=1); null = not evaluated yet
+    int32_t item = -1; int32_t depth = 0;
     int64_t dev = -1;                                      // id in the device store (-1 = the root / no store)
-    int64_t child_dev[2] = {-1, -1};                       // store ids of the evaluated children
-    int64_t gchild_dev[2][2] = {{-1, -1}, {-1, -1}};       // ... and of their children (same launch)
-    double bound = 0; Relax self;                          // own relaxation (bound == self.profit)
-    Relax child[2];                                        // cached children (x=0, x=1)
-    Relax gchild[2][2];                                    // cached children of child v (lpx_knapsack_relax_batch2)
+    Relax self; double bound = 0;                          // own relaxation (bound == self.profit)
+    int8_t val = 0; bool queued = false;                   // queued: its children are part of the launch being assembled
     // fixed decisions in ascending item index (the reference's Assigned without the undecided entries)
     void list(std::vector<int32_t>& idx, std::vector<int8_t>& val) const {
         std::vector<std::pair<int32_t, int8_t>> e; e.reserve((size_t)depth);
@@ -51,7 +57,6 @@ struct KNode {
         for (auto& x : e) { idx.push_back(x.first); val.push_back(x.second); }
     }
 };
-using NodeP = std::unique_ptr<KNode>;
 
 struct Heap {                                              // SimpleMaxHeap<Node>, :494-547
     // the key sits beside the pointer: a sift compares array entries only (the reference compares node.Bound through the
@@ -86,42 +91,60 @@ struct Search {
     lpx_knapsack* k; int n; double cap;
     std::vector<double> profit, weight; std::vector<int32_t> order;
     double best = -INFINITY; std::vector<int32_t> bestX; bool has_best = false;
-    int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0;
+    int64_t popped = 0, expanded = 0, relaxations = 0, max_heap = 0, launches = 0, jobs_run = 0;
     int64_t redundant_popped = 0, redundant_relax = 0;   // replicated warm-up on ranks != 0
     double dev_ms = 0;                                   // wall time inside the lpx_knapsack_* calls (launch + wait)
-    int spec = 64;
+    int spec = 256;                                      // evaluated leaves expanded ahead of the search per launch
     std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
-
-    // evaluates `jobs` = (node, fixed item, value) in one launch
-    struct Job { KNode* node; int item; int v; Relax* out; Relax* gout; };   // gout: two slots for the job's own children, or null
+    std::deque<KNode> arena;                             // the evaluated tree (stable addresses)
+    Heap leaves;                                         // evaluated, unexpanded, still worth expanding: keyed by bound
     bool depth2 = false;                                 // one launch also evaluates each job's two children
     bool use_store = false;                              // device-resident node lists (lpx_knapsack_expand_batch)
+
+    KNode* alloc() { arena.emplace_back(); return &arena.back(); }
+    bool worth_expanding(const KNode* x) const           // would the search branch on it if it popped it now?
+    { return x->self.frac >= 0 && x->self.weight <= cap + EPS && x->self.profit > best + EPS; }
+    void offer_leaf(KNode* x) { if (!x->kid[0] && !x->kid[1] && worth_expanding(x)) leaves.push(x); }
+
+    struct Clock { double& acc; std::chrono::steady_clock::time_point t0;
+                   explicit Clock(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+
+    void eval_root(KNode* root)
+    {
+        double p = 0, w = 0, fv = 0; int32_t fr = -1;
+        const int32_t off[2] = {0, 0}; const int32_t fidx[1] = {0}; const int8_t fval[1] = {0};
+        int rc;
+        { Clock c(dev_ms);
+          rc = test_relax ? test_relax(1, off, fidx, fval, &p, &w, &fr, &fv) : lpx_knapsack_relax_batch(k, 1, off, fidx, fval, &p, &w, &fr, &fv); }
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        ++launches;
+        root->self.profit = p; root->self.weight = w; root->self.frac = fr; root->self.fracval = fv; root->self.valid = true;
+        root->bound = p;
+    }
+
+    // one launch: child `v` of every job's node (its fractional item fixed to v) and, with depth2, that child's two children
+    struct Job { KNode* node; int v; };
     void run_jobs(std::vector<Job>& jobs)
     {
         if (jobs.empty()) return;
-        struct Clock { double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); bool on = false;
-                       void start() { t0 = std::chrono::steady_clock::now(); on = true; }
-                       void stop() { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); on = false; } } clk{dev_ms};
         const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
         std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
-        if (use_store && jobs[0].item >= 0) {
-            // 32 bytes per job: (parent id, item, value); the device derives, stores and evaluates the child
-            std::vector<int64_t> par(jobs.size()), ch(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
-            for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = jobs[j].item; vv[j] = (int8_t)jobs[j].v; }
-            clk.start();
-            int rc = lpx_knapsack_expand_batch(k, (int)jobs.size(), par.data(), it.data(), vv.data(), ch.data(), p.data(), w.data(), fr.data(), fv.data());
-            clk.stop();
+        std::vector<int64_t> ch(jobs.size(), -1);
+        if (use_store) {
+            // 48 bytes per job: (parent id, item, value); the device derives, stores and evaluates the child
+            std::vector<int64_t> par(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
+            for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = order[jobs[j].node->self.frac]; vv[j] = (int8_t)jobs[j].v; }
+            int rc;
+            { Clock c(dev_ms);
+              rc = lpx_knapsack_expand_batch(k, (int)jobs.size(), par.data(), it.data(), vv.data(), ch.data(), p.data(), w.data(), fr.data(), fv.data()); }
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
-            for (size_t j = 0; j < jobs.size(); ++j) {
-                KNode* nd = jobs[j].node; const int v = jobs[j].v;
-                nd->child_dev[v] = ch[j]; nd->gchild_dev[v][0] = ch[j] + 1; nd->gchild_dev[v][1] = ch[j] + 2;
-            }
         } else {
             std::vector<int32_t> off(jobs.size() + 1, 0), fidx, li; std::vector<int8_t> fval, lv;
             for (size_t j = 0; j < jobs.size(); ++j) {
                 jobs[j].node->list(li, lv);                  // ascending index order (:442)
-                const int it = jobs[j].item;
-                bool placed = it < 0;
+                const int it = order[jobs[j].node->self.frac];
+                bool placed = false;
                 for (size_t e = 0; e < li.size(); ++e) {
                     if (!placed && it < li[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
                     fidx.push_back(li[e]); fval.push_back(lv[e]);
@@ -129,35 +152,43 @@ struct Search {
                 if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
                 off[j + 1] = (int32_t)fidx.size();
             }
-            if (fidx.empty()) { fidx.push_back(0); fval.push_back(0); }
-            clk.start();
-            int rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                   : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                            : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data());
-            clk.stop();
+            int rc;
+            { Clock c(dev_ms);
+              rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                 : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                          : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data()); }
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
         }
-        ++launches;
+        ++launches; jobs_run += (int64_t)jobs.size();
+        auto fill = [&](KNode* x, KNode* parent, int item, int v, size_t o, int64_t dev) {
+            x->parent = parent; x->item = item; x->val = (int8_t)v; x->depth = parent->depth + 1; x->dev = dev;
+            x->self.profit = p[o]; x->self.weight = w[o]; x->self.frac = fr[o]; x->self.fracval = fv[o]; x->self.valid = true;
+            x->bound = p[o];
+        };
         for (size_t j = 0; j < jobs.size(); ++j) {
-            Relax& r = *jobs[j].out;
-            r.profit = p[st * j]; r.weight = w[st * j]; r.frac = fr[st * j]; r.fracval = fv[st * j]; r.valid = true;
-            if (depth2 && jobs[j].gout) {
-                for (int c = 0; c < 2; ++c) {
-                    Relax& g = jobs[j].gout[c];
-                    const size_t o = st * j + 1 + c;
-                    g.valid = fr[o] != -2;
-                    if (g.valid) { g.profit = p[o]; g.weight = w[o]; g.frac = fr[o]; g.fracval = fv[o]; }
+            KNode* nd = jobs[j].node; const int v = jobs[j].v;
+            KNode* c = alloc();
+            fill(c, nd, order[nd->self.frac], v, st * j, ch[j]);
+            nd->kid[v] = c; nd->queued = false;
+            if (depth2 && c->self.frac >= 0) {
+                for (int cc = 0; cc < 2; ++cc) {
+                    const size_t o = st * j + 1 + (size_t)cc;
+                    if (fr[o] == -2) continue;                  // the child has nothing to branch on
+                    KNode* g = alloc();
+                    fill(g, c, order[c->self.frac], cc, o, ch[j] < 0 ? -1 : ch[j] + 1 + cc);
+                    c->kid[cc] = g;
+                    if (worth_expanding(c)) offer_leaf(g);
                 }
-            }
+            } else if (!depth2) offer_leaf(c);
         }
     }
 
-    // relaxed vector of a node (host, O(n); only on incumbent updates)
-    std::vector<double> relaxed_of(const KNode& nd, int item, int v, const Relax& r) const
+    // relaxed vector of an evaluated node (host, O(n); only on incumbent updates)
+    std::vector<double> relaxed_of(const KNode& nd) const
     {
+        const Relax& r = nd.self;
         std::vector<int8_t> as(n, -1);
         for (const KNode* q = &nd; q && q->item >= 0; q = q->parent) as[q->item] = q->val;
-        if (item >= 0) as[item] = (int8_t)v;
         std::vector<double> x(n, 0.0);
         for (int i = 0; i < n; ++i) if (as[i] == 1) x[i] = 1.0;
         double fixedw = 0; for (int i = 0; i < n; ++i) if (as[i] == 1) fixedw += weight[i];
@@ -175,9 +206,10 @@ struct Search {
         return x;
     }
 
-    void consider_child(Heap& pq, std::vector<NodeP>& store, KNode* node, int item, int v)
+    void consider_child(Heap& pq, KNode* node, int v)
     {
-        const Relax& r = node->child[v];
+        KNode* ch = node->kid[v];
+        const Relax& r = ch->self;
         if (r.weight > cap + EPS) return;                                   // :215 / :277 INFEASIBLE
         if (r.profit > best + EPS) {                                        // :223 / :285
             const bool allInt = (r.frac < 0) || std::fabs(r.fracval - std::nearbyint(r.fracval)) < EPS;
@@ -185,19 +217,12 @@ struct Search {
             if (allInt && feasible) {                                       // :228-236
                 if (r.profit > best + EPS) {
                     best = r.profit; has_best = true;
-                    std::vector<double> x = relaxed_of(*node, item, v, r);
+                    std::vector<double> x = relaxed_of(*ch);
                     bestX.assign(n, 0);
                     for (int i = 0; i < n; ++i) bestX[i] = (int32_t)std::nearbyint(x[i]);
                 }
             } else {                                                        // :239-248
-                NodeP ch(new KNode());
-                ch->parent = node; ch->item = item; ch->val = (int8_t)v; ch->depth = node->depth + 1;
-                ch->dev = node->child_dev[v];
-                ch->bound = r.profit; ch->self = r;
-                ch->child[0] = node->gchild[v][0]; ch->child[1] = node->gchild[v][1];   // already evaluated with the parent's launch
-                ch->child_dev[0] = node->gchild_dev[v][0]; ch->child_dev[1] = node->gchild_dev[v][1];
-                pq.push(ch.get());
-                store.push_back(std::move(ch));
+                pq.push(ch);                                                // already evaluated, its children possibly too
                 max_heap = std::max<int64_t>(max_heap, (int64_t)pq.d.size());
             }
         }
@@ -205,44 +230,54 @@ struct Search {
     }
 
     // one pop of the main loop (:118-328); returns false when the heap is empty
-    bool step(Heap& pq, std::vector<NodeP>& store)
+    bool step(Heap& pq)
     {
         if (pq.d.empty()) return false;
         KNode* node = pq.pop();
         ++popped;                                                           // :121
         if (node->bound <= best + EPS) return true;                         // :124
         ++expanded;
-        ++relaxations;                                                      // :127 recompute (identical to the cached one)
+        ++relaxations;                                                      // :127 recompute (identical to the stored one)
         const Relax& self = node->self;
         if (self.frac == -1) {                                              // :147-177
             if (self.weight <= cap + EPS && self.profit > best + EPS) {
                 best = self.profit; has_best = true;
-                std::vector<double> x = relaxed_of(*node, -1, 0, self);
+                std::vector<double> x = relaxed_of(*node);
                 bestX.assign(n, 0);
                 for (int i = 0; i < n; ++i) bestX[i] = x[i] >= 0.5 ? 1 : 0;
             }
             return true;
         }
-        const int item = order[self.frac];                                  // :180
-        if (!node->child[0].valid || !node->child[1].valid) {
-            // one launch: this node's children plus those of the nodes near the top of the heap
+        if (!node->kid[0] || !node->kid[1]) {
+            // one launch: this node's children plus those of the best evaluated leaves -- the nodes the search pops next
             std::vector<Job> jobs;
-            jobs.push_back({node, item, 0, &node->child[0], node->gchild[0]});
-            jobs.push_back({node, item, 1, &node->child[1], node->gchild[1]});
-            const size_t lim = std::min<size_t>(pq.d.size(), (size_t)spec);
-            for (size_t i = 0; i < lim; ++i) {
-                KNode* o = pq.d[i].n;
-                if (o->child[0].valid || o->self.frac < 0 || o->bound <= best + EPS) continue;
-                const int it = order[o->self.frac];
-                jobs.push_back({o, it, 0, &o->child[0], o->gchild[0]});
-                jobs.push_back({o, it, 1, &o->child[1], o->gchild[1]});
+            for (int v = 0; v < 2; ++v) if (!node->kid[v]) jobs.push_back({node, v});
+            node->queued = true;
+            int taken = 0;
+            while (taken < spec && !leaves.d.empty()) {
+                KNode* o = leaves.pop();
+                if (o->queued || o->kid[0] || o->kid[1] || !worth_expanding(o)) continue;   // stale entry
+                o->queued = true;
+                jobs.push_back({o, 0}); jobs.push_back({o, 1});
+                ++taken;
             }
             run_jobs(jobs);
         }
         relaxations += 2;
-        consider_child(pq, store, node, item, 0);                           // LEFT  x=0, :207-264
-        consider_child(pq, store, node, item, 1);                           // RIGHT x=1, :267-327
+        consider_child(pq, node, 0);                                        // LEFT  x=0, :207-264
+        consider_child(pq, node, 1);                                        // RIGHT x=1, :267-327
         return true;
+    }
+
+    // after the frontier is split over the ranks: speculate only below nodes this rank owns
+    void reseed_leaves(const Heap& pq)
+    {
+        leaves.d.clear();
+        std::function<void(KNode*)> walk = [&](KNode* x) {
+            if (!x->kid[0] && !x->kid[1]) { offer_leaf(x); return; }
+            for (int v = 0; v < 2; ++v) if (x->kid[v] && worth_expanding(x)) walk(x->kid[v]);
+        };
+        for (auto& e : pq.d) walk(e.n);
     }
 };
 
@@ -280,7 +315,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     struct Guard { lpx_knapsack* k; ~Guard() { lpx_knapsack_destroy(k); } } guard{kh};
     S.k = kh;
     S.bestX.assign(n, 0);
-    S.spec = opt.concurrent_nodes > 1 ? opt.concurrent_nodes : 64;
+    S.spec = opt.concurrent_nodes > 1 ? opt.concurrent_nodes : 256;
     {   // every launch also evaluates the children of the nodes it evaluates (LPX_KNAP_DEPTH2=0: off)
         const char* e = std::getenv("LPX_KNAP_DEPTH2");
         S.depth2 = !S.test_relax && kh && lpx_knapsack_has_prefix(kh) && !(e && e[0] == '0');
@@ -289,13 +324,10 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
         S.use_store = S.depth2 && !(e2 && e2[0] == '0');
     }
 
-    std::vector<NodeP> store;
     Heap pq;
-    NodeP root(new KNode());                                                // :102-113
-    // (with the device store the root's children are derived there when the root is popped, so that their lists exist)
-    { std::vector<Search::Job> j{{root.get(), -1, 0, &root->self, S.use_store ? nullptr : root->child}}; S.run_jobs(j); S.relaxations++; }
-    root->bound = root->self.profit;
-    pq.push(root.get()); store.push_back(std::move(root));
+    KNode* root = S.alloc();                                                // :102-113
+    S.eval_root(root); S.relaxations++;
+    pq.push(root);
     S.max_heap = 1;
 
     const int world = std::max(1, opt.world), rank = opt.rank;
@@ -308,12 +340,13 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
             for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i].n);
             pq.d.swap(mine.d);
             replicated = false;
+            S.reseed_leaves(pq);
             if (rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }   // rank 0 accounts for the warm-up
         }
         bool more = true;
         for (int it = 0; it < round && more; ++it) {
             if (cap_nodes > 0 && S.popped >= cap_nodes) { more = false; break; }
-            more = S.step(pq, store);
+            more = S.step(pq);
             if (replicated && pq.d.size() >= (size_t)(4 * world)) break;
         }
         if (world > 1 && !replicated && opt.allreduce_max) {

@@ -244,14 +244,18 @@ __global__ __launch_bounds__(256) void knap_relax_prefix(KnParams P, KnPrefix X)
 // ------------------------------------------------------------------------------------------------
 // Device-resident node store.  The best-first loop creates every node as "its parent plus one decision"
 // (Models/BranchAndBoundKnapsack.cs:207-209,:267-269), so a node's fixed list never has to travel: the parent's list
-// already sits in HBM, the kernel writes the child's list next to it (ascending item index, the decision packed as
-// idx | val << 31) and evaluates the child -- and the child's own two children, as knap_relax_prefix<true> does -- from
-// the parent's entries in registers plus the new decision(s) as extras.  A job is 32 bytes of H2D instead of the whole
-// list (100-250 entries per node at config 5), and the host keeps a heap of ids.
+// already sits in HBM, the kernel writes the child's list next to it and evaluates the child -- and the child's own two
+// children, as knap_relax_prefix<true> does -- from the parent's entries plus the new decision(s) as extras.  A job is
+// 48 bytes instead of the whole list (100-250 entries per node at config 5), and the host keeps a heap of ids.
+// A stored list is ordered by RATIO RANK (the position in the sorted arrays), one word per decision: rank | value << 31.
+// In that order the fixed weight in front of a position t is a prefix of the list, which is what the wide search needs;
+// the host turns ranks back into item indices (lpx_knapsack_node_list).
 // ------------------------------------------------------------------------------------------------
 struct KnJob { const uint32_t* parent; uint32_t* child; uint32_t* g0; uint32_t* g1; int32_t depth; int32_t item; int32_t val; int32_t pad; };
 
-__global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const KnJob* __restrict__ jobs, const int32_t* __restrict__ ord)
+// Deep nodes (more than KW_CAP decisions): one binary search per relaxation, every probe one wave reduction over the
+// parent's entries.  17 dependent probes per relaxation at n = 100 000 -- the form the wide kernel below replaces.
+__global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const KnJob* __restrict__ jobs)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int job = blockIdx.x * 4 + wave;
@@ -260,33 +264,32 @@ __global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const
     const int n = P.n, d = J.depth;
     const uint32_t* __restrict__ par = J.parent;
     // the new decision
-    const int xi = J.item;
-    const int x1pos = P.pos[xi]; const double x1w = P.w0[xi], x1p = P.p0[xi]; const int x1val = J.val;
+    const int x1pos = P.pos[J.item]; const double x1w = P.ws[x1pos], x1p = P.ps[x1pos]; const int x1val = J.val;
     int cpos[KP_CACHE]; double cw[KP_CACHE], cp[KP_CACHE];
     double w1 = 0.0, p1 = 0.0;
-    int before = 0;                                     // parent entries with a smaller item index (insertion point)
+    int before = 0;                                     // parent entries with a smaller rank (insertion point)
 #pragma unroll
     for (int k = 0; k < KP_CACHE; ++k) {
         const int e = lane + 64 * k;
         cpos[k] = INT_MAX; cw[k] = 0.0; cp[k] = 0.0;
         if (e < d) {
             const uint32_t v = par[e];
-            const int i = (int)(v & 0x7fffffffu);
-            cpos[k] = P.pos[i]; cw[k] = P.w0[i]; cp[k] = P.p0[i];
+            const int r = (int)(v & 0x7fffffffu);
+            cpos[k] = r; cw[k] = P.ws[r]; cp[k] = P.ps[r];
             if (v >> 31) { w1 += cw[k]; p1 += cp[k]; }
-            before += (i < xi) ? 1 : 0;
-            J.child[e + ((i > xi) ? 1 : 0)] = v;
+            before += (r < x1pos) ? 1 : 0;
+            J.child[e + ((r > x1pos) ? 1 : 0)] = v;
         }
     }
-    for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {            // deeper nodes: the tail stays in memory
+    for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {            // the tail stays in memory
         const uint32_t v = par[e];
-        const int i = (int)(v & 0x7fffffffu);
-        if (v >> 31) { w1 += P.w0[i]; p1 += P.p0[i]; }
-        before += (i < xi) ? 1 : 0;
-        J.child[e + ((i > xi) ? 1 : 0)] = v;
+        const int r = (int)(v & 0x7fffffffu);
+        if (v >> 31) { w1 += P.ws[r]; p1 += P.ps[r]; }
+        before += (r < x1pos) ? 1 : 0;
+        J.child[e + ((r > x1pos) ? 1 : 0)] = v;
     }
     before = (int)wave_sum_f64((double)before);
-    if (lane == 0) J.child[before] = (uint32_t)xi | ((uint32_t)x1val << 31);
+    if (lane == 0) J.child[before] = (uint32_t)x1pos | ((uint32_t)x1val << 31);
     const double W1n = wave_sum_f64(w1) + (x1val == 1 ? x1w : 0.0), P1n = wave_sum_f64(p1) + (x1val == 1 ? x1p : 0.0);
 
     auto solve = [&](int xpos, int xval, double xw, double xp, int slot) {
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const
 #pragma unroll
             for (int k = 0; k < KP_CACHE; ++k) if (cpos[k] < t) { a += cw[k]; b += cp[k]; }
             for (int e = lane + 64 * KP_CACHE; e < d; e += 64) {
-                const int i = (int)(par[e] & 0x7fffffffu);
-                if (P.pos[i] < t) { a += P.w0[i]; b += P.p0[i]; }
+                const int r = (int)(par[e] & 0x7fffffffu);
+                if (r < t) { a += P.ws[r]; b += P.ps[r]; }
             }
             fw = wave_sum_f64(a); fp = wave_sum_f64(b);
             if (x1pos < t) { fw += x1w; fp += x1p; }
@@ -348,21 +351,179 @@ __global__ __launch_bounds__(256) void knap_expand(KnParams P, KnPrefix X, const
     solve(frac, 1, xw, xp, 3 * job + 2);
     // the lists of those two children (the child's list plus its fractional item, value 0 / 1): every relaxation the host
     // caches has its node in the store, so the host never has to send a list
-    const int x2 = ord[frac];
+    const int x2 = frac;
     int before2 = 0;
     for (int e = lane; e < d; e += 64) {
         const uint32_t v = par[e];
-        const int i = (int)(v & 0x7fffffffu);
-        before2 += (i < x2) ? 1 : 0;
-        const int dst = e + ((i > xi) ? 1 : 0) + ((i > x2) ? 1 : 0);
+        const int r = (int)(v & 0x7fffffffu);
+        before2 += (r < x2) ? 1 : 0;
+        const int dst = e + ((r > x1pos) ? 1 : 0) + ((r > x2) ? 1 : 0);
         J.g0[dst] = v; J.g1[dst] = v;
     }
     before2 = (int)wave_sum_f64((double)before2);
     if (lane == 0) {
-        const int p1 = before + ((xi > x2) ? 1 : 0), p2 = before2 + ((x2 > xi) ? 1 : 0);
-        const uint32_t e1 = (uint32_t)xi | ((uint32_t)x1val << 31);
-        J.g0[p1] = e1; J.g1[p1] = e1;
-        J.g0[p2] = (uint32_t)x2; J.g1[p2] = (uint32_t)x2 | 0x80000000u;
+        const int q1 = before + ((x1pos > x2) ? 1 : 0), q2 = before2 + ((x2 > x1pos) ? 1 : 0);
+        const uint32_t e1 = (uint32_t)x1pos | ((uint32_t)x1val << 31);
+        J.g0[q1] = e1; J.g1[q1] = e1;
+        J.g0[q2] = (uint32_t)x2; J.g1[q2] = (uint32_t)x2 | 0x80000000u;
+    }
+}
+
+// The wide form (nodes of at most KW_CAP decisions -- every node of config 5).  The break position t* is the smallest t
+// with  g(t) = W1 + PW[t] - fixed_before(t) > cap + EPS,  g monotone in t.  Instead of halving [1, n] with one probe per
+// step (17 dependent memory round trips per relaxation, 51 per job: the 20 us the r02 trace shows for this kernel), the
+// 64 lanes probe 64 positions at once:
+//   * the parent's list is ordered by rank, so fixed_before(t) = prefix[#entries with rank < t]: each lane holds eight
+//     consecutive entries, one wave scan gives the exclusive prefixes, ranks + prefixes go to LDS (10 KB per wave) and a
+//     lane answers its own t by a binary search there (<= 9 LDS reads, no memory traffic);
+//   * a round = one gather PW[t_lane] + one ballot; [1, n + 1] shrinks by 64x per round (three rounds at n = 100 000),
+//     and the first round is aimed at where the answer almost always is: within +-32 positions of the branching item
+//     (fixing the parent's fractional item to 0 / 1 moves the break by about one undecided item).
+// Same predicate, same t*, same closing arithmetic as the deep form above: identical outputs for integer data (sums
+// exact below 2^53), 1e-9 relative otherwise, as for the host-list kernels.
+static constexpr int KW_PER = 8;
+static constexpr int KW_CAP = 64 * KW_PER;
+struct KwWave { double fw[KW_CAP + 1]; double fp[KW_CAP + 1]; int rank[KW_CAP + 1]; int pad; };
+
+__global__ __launch_bounds__(256) void knap_expand_w(KnParams P, KnPrefix X, const KnJob* __restrict__ jobs)
+{
+    __shared__ KwWave lds[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + wave;
+    const bool live = job < P.count;
+    KwWave& L = lds[wave];
+    const KnJob J = jobs[live ? job : 0];
+    const int n = P.n, d = live ? J.depth : 0;
+    const uint32_t* __restrict__ par = J.parent;
+    const int x1pos = P.pos[J.item]; const double x1w = P.ws[x1pos], x1p = P.ps[x1pos]; const int x1val = J.val;
+
+    uint32_t ev[KW_PER]; int rk[KW_PER]; double wk[KW_PER], pk[KW_PER];
+#pragma unroll
+    for (int h = 0; h < KW_PER / 4; ++h) {
+        const int e0 = lane * KW_PER + 4 * h;
+        uint4 q = {0u, 0u, 0u, 0u};
+        if (e0 < d) q = *reinterpret_cast<const uint4*>(par + e0);        // lists are carved in 16-byte granules
+        ev[4 * h + 0] = q.x; ev[4 * h + 1] = q.y; ev[4 * h + 2] = q.z; ev[4 * h + 3] = q.w;
+    }
+    double lw = 0.0, lp = 0.0, w1 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KW_PER; ++k) {
+        const int e = lane * KW_PER + k;
+        const bool valid = e < d;
+        const int r = valid ? (int)(ev[k] & 0x7fffffffu) : INT_MAX;
+        rk[k] = r;
+        wk[k] = valid ? P.ws[r] : 0.0; pk[k] = valid ? P.ps[r] : 0.0;
+        lw += wk[k]; lp += pk[k];
+        if (valid && (ev[k] >> 31)) { w1 += wk[k]; p1 += pk[k]; }
+        if (valid && live) J.child[e + ((r > x1pos) ? 1 : 0)] = ev[k];
+    }
+    {   // exclusive prefixes over the lanes, then per entry
+        double sw = wave_incl_scan_sum(lw), sp = wave_incl_scan_sum(lp);
+        double rw = __shfl_up(sw, 1, 64), rp = __shfl_up(sp, 1, 64);
+        if (lane == 0) { rw = 0.0; rp = 0.0; }
+#pragma unroll
+        for (int k = 0; k < KW_PER; ++k) {
+            const int e = lane * KW_PER + k;
+            L.rank[e] = rk[k]; L.fw[e] = rw; L.fp[e] = rp;
+            rw += wk[k]; rp += pk[k];
+        }
+        if (lane == 63) { L.rank[KW_CAP] = INT_MAX; L.fw[KW_CAP] = rw; L.fp[KW_CAP] = rp; }
+    }
+    __syncthreads();
+    if (!live) return;
+    const double W1n = wave_sum_f64(w1) + (x1val == 1 ? x1w : 0.0), P1n = wave_sum_f64(p1) + (x1val == 1 ? x1p : 0.0);
+    // #entries of the parent's list with rank < t (per lane, its own t): binary search in LDS
+    int s0 = 1; while (2 * s0 <= d) s0 *= 2;
+    auto below = [&](int t) {
+        int idx = 0;
+        if (d > 0)
+            for (int s = s0; s >= 1; s >>= 1)
+                if (idx + s <= KW_CAP && L.rank[idx + s - 1] < t) idx += s;
+        return idx;
+    };
+    const int before = below(x1pos);
+    if (lane == 0) J.child[before] = (uint32_t)x1pos | ((uint32_t)x1val << 31);
+
+    auto solve = [&](int xpos, int xval, double xw, double xp, int hint, int slot) {
+        const double W1 = W1n + (xval == 1 ? xw : 0.0), P1 = P1n + (xval == 1 ? xp : 0.0);
+        if (W1 > P.cap + KEPS) {                                        // :455-456
+            if (lane == 0) { P.out_profit[slot] = P1; P.out_weight[slot] = W1; P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0; }
+            return -1;
+        }
+        auto fixed_before = [&](int t, double& fw, double& fp) {
+            const int c = below(t);
+            fw = L.fw[c]; fp = L.fp[c];
+            if (x1pos < t) { fw += x1w; fp += x1p; }
+            if (xpos < t) { fw += xw; fp += xp; }
+        };
+        int lo = 1, hi = n + 1;                                         // t* in [lo, hi]; g(hi) holds or hi == n + 1
+        // one round: lanes probe base + lane * stride (inside [lo, hi)), the ballots move lo / hi
+        auto round = [&](int base, int stride) {
+            const int t = base + lane * stride;
+            const bool in = t >= lo && t < hi;
+            bool over = false;
+            if (in) {
+                double fw, fp;
+                fixed_before(t, fw, fp);
+                over = W1 + (X.PW[t] - fw) > P.cap + KEPS;
+            }
+            const unsigned long long yes = __ballot(in && over), no = __ballot(in && !over);
+            if (yes) hi = base + (int)__builtin_ctzll(yes) * stride;
+            if (no) lo = base + (63 - (int)__builtin_clzll(no)) * stride + 1;
+        };
+        if (hint >= 1 && hint <= n) round(max(1, hint - 31), 1);
+        while (lo < hi) {
+            const int c = hi - lo, stride = (c + 63) >> 6;
+            round(lo + stride - 1, stride);
+        }
+        double fw, fp;
+        if (lo == n + 1) {
+            fixed_before(n, fw, fp);
+            if (lane == 0) {
+                P.out_profit[slot] = P1 + (X.PP[n] - fp); P.out_weight[slot] = W1 + (X.PW[n] - fw);
+                P.out_frac[slot] = -1; P.out_fracval[slot] = 0.0;
+            }
+            return -1;
+        }
+        const int j = lo - 1;
+        fixed_before(j, fw, fp);
+        double w = W1 + (X.PW[j] - fw), p = P1 + (X.PP[j] - fp);
+        int frac = -1; double fv = 0.0;
+        const double wi = P.ws[j];
+        const double remain = P.cap - w;
+        if (remain > KEPS && wi > KEPS) {                               // :476-484
+            fv = remain / wi;
+            p += P.ps[j] * fv;
+            w += wi * fv;
+            frac = j;
+        }
+        if (lane == 0) { P.out_profit[slot] = p; P.out_weight[slot] = w; P.out_frac[slot] = frac; P.out_fracval[slot] = fv; }
+        return frac;
+    };
+    const int frac = solve(INT_MAX, 0, 0.0, 0.0, x1pos + 1, 3 * job);
+    if (frac < 0) {
+        if (lane == 0) { P.out_frac[3 * job + 1] = -2; P.out_frac[3 * job + 2] = -2; }
+        return;
+    }
+    const double xw = P.ws[frac], xp = P.ps[frac];
+    solve(frac, 0, xw, xp, frac + 1, 3 * job + 1);
+    solve(frac, 1, xw, xp, frac + 1, 3 * job + 2);
+    // the lists of the child's two children
+    const int x2 = frac;
+    const int before2 = below(x2);
+#pragma unroll
+    for (int k = 0; k < KW_PER; ++k) {
+        const int e = lane * KW_PER + k;
+        if (e < d) {
+            const int dst = e + ((rk[k] > x1pos) ? 1 : 0) + ((rk[k] > x2) ? 1 : 0);
+            J.g0[dst] = ev[k]; J.g1[dst] = ev[k];
+        }
+    }
+    if (lane == 0) {
+        const int q1 = before + ((x1pos > x2) ? 1 : 0), q2 = before2 + ((x2 > x1pos) ? 1 : 0);
+        const uint32_t e1 = (uint32_t)x1pos | ((uint32_t)x1val << 31);
+        J.g0[q1] = e1; J.g1[q1] = e1;
+        J.g0[q2] = (uint32_t)x2; J.g1[q2] = (uint32_t)x2 | 0x80000000u;
     }
 }
 
@@ -388,7 +549,7 @@ struct lpx_knapsack {
     std::vector<uint32_t*> chunks; size_t chunk_used = 0;
     std::vector<uint32_t*> node_list; std::vector<int32_t> node_depth;      // node id -> (list, depth)
     char* d_jobs = nullptr; char* h_jobs = nullptr; size_t jobs_cap = 0;
-    int32_t* d_ord = nullptr;                                                // ratio rank -> original index
+    bool wide = true;                                                        // LPX_KNAP_WIDE=0: always the one-probe-per-step kernel
 };
 
 static constexpr size_t KN_CHUNK_WORDS = (size_t)16 << 20;                   // 64 MiB of uint32
@@ -402,7 +563,7 @@ void lpx_knapsack_destroy(lpx_knapsack* k)
     hipFree(k->ws); hipFree(k->ps); hipFree(k->w0); hipFree(k->p0); hipFree(k->pos); hipFree(k->PW); hipFree(k->PP);
     hipFree(k->d_off); hipFree(k->d_fidx); hipFree(k->d_frac); hipFree(k->d_fval);
     hipFree(k->d_profit); hipFree(k->d_weight); hipFree(k->d_fracval);
-    hipFree(k->d_in); hipFree(k->d_out); hipFree(k->d_jobs); hipFree(k->d_ord);
+    hipFree(k->d_in); hipFree(k->d_out); hipFree(k->d_jobs);
     for (uint32_t* c : k->chunks) hipFree(c);
     if (k->h_jobs) hipHostFree(k->h_jobs);
     if (k->h_in) hipHostFree(k->h_in);
@@ -444,7 +605,7 @@ int lpx_knapsack_create(const double* profit, const double* weight, int n, doubl
     up((void**)&k->ws, ws.data(), sizeof(double) * n); up((void**)&k->ps, ps.data(), sizeof(double) * n);
     up((void**)&k->w0, weight, sizeof(double) * n); up((void**)&k->p0, profit, sizeof(double) * n);
     up((void**)&k->pos, pos.data(), sizeof(int32_t) * n);
-    up((void**)&k->d_ord, k->order.data(), sizeof(int32_t) * n);
+    { const char* ev = std::getenv("LPX_KNAP_WIDE"); k->wide = !(ev && ev[0] == '0'); }
     // running sums in ratio order (left-to-right, as the reference accumulates) for the prefix-sum kernel
     std::vector<double> PW(n + 1, 0.0), PP(n + 1, 0.0);
     bool nonneg = true;
@@ -578,8 +739,10 @@ int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent,
         k->chunk_used += need;
         return 0;
     };
+    int maxdepth = 0;
     for (int j = 0; j < count; ++j) {
         const int d = parent[j] < 0 ? 0 : k->node_depth[(size_t)parent[j]];
+        maxdepth = std::max(maxdepth, d);
         uint32_t *c0 = nullptr, *g0 = nullptr, *g1 = nullptr;
         int rc = carve((size_t)d + 1, &c0); if (rc) return rc;
         rc = carve((size_t)d + 2, &g0); if (rc) return rc;
@@ -613,7 +776,11 @@ int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent,
     P.out_profit = reinterpret_cast<double*>(k->h_out + o_p); P.out_weight = reinterpret_cast<double*>(k->h_out + o_w);
     P.out_fracval = reinterpret_cast<double*>(k->h_out + o_fv); P.out_frac = reinterpret_cast<int32_t*>(k->h_out + o_fr);
     KnPrefix X; X.PW = k->PW; X.PP = k->PP;
-    hipLaunchKernelGGL(knap_expand, dim3((count + 3) / 4), dim3(256), 0, s, P, X, reinterpret_cast<const KnJob*>(k->h_jobs), (const int32_t*)k->d_ord);
+    // every node of the batch within the wide kernel's list capacity -> 64 probes per round; deeper nodes -> one probe per step
+    if (maxdepth <= KW_CAP && k->wide)
+        hipLaunchKernelGGL(knap_expand_w, dim3((count + 3) / 4), dim3(256), 0, s, P, X, reinterpret_cast<const KnJob*>(k->h_jobs));
+    else
+        hipLaunchKernelGGL(knap_expand, dim3((count + 3) / 4), dim3(256), 0, s, P, X, reinterpret_cast<const KnJob*>(k->h_jobs));
     LPX_HIP_TRY(hipGetLastError());
     LPX_HIP_TRY(hipStreamSynchronize(s));
     if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * nout);
@@ -628,12 +795,15 @@ int lpx_knapsack_node_list(lpx_knapsack* k, int64_t node, int32_t* idx, int8_t* 
     if (!k || node < 0 || node >= (int64_t)k->node_list.size()) { set_error("lpx_knapsack_node_list: unknown node id"); return LPX_EINVAL; }
     const int d = k->node_depth[(size_t)node];
     if (depth) *depth = d;
-    if (idx && val && cap > 0) {
-        const int c = d < cap ? d : cap;
-        std::vector<uint32_t> tmp((size_t)(c > 0 ? c : 1));
+    if (idx && val && cap > 0 && d > 0) {
+        std::vector<uint32_t> tmp((size_t)d);
         LPX_HIP_TRY(hipStreamSynchronize(k->stream));
-        if (c > 0) LPX_HIP_TRY(hipMemcpy(tmp.data(), k->node_list[(size_t)node], sizeof(uint32_t) * c, hipMemcpyDeviceToHost));
-        for (int e = 0; e < c; ++e) { idx[e] = (int32_t)(tmp[e] & 0x7fffffffu); val[e] = (int8_t)(tmp[e] >> 31); }
+        LPX_HIP_TRY(hipMemcpy(tmp.data(), k->node_list[(size_t)node], sizeof(uint32_t) * d, hipMemcpyDeviceToHost));
+        // the store keeps ratio ranks; the caller gets item indices in ascending order (the reference's Assigned order)
+        std::vector<std::pair<int32_t, int8_t>> ent((size_t)d);
+        for (int e = 0; e < d; ++e) ent[(size_t)e] = {k->order[(size_t)(tmp[e] & 0x7fffffffu)], (int8_t)(tmp[e] >> 31)};
+        std::sort(ent.begin(), ent.end());
+        for (int e = 0; e < d && e < cap; ++e) { idx[e] = ent[(size_t)e].first; val[e] = ent[(size_t)e].second; }
     }
     return 0;
 }

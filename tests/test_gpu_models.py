@@ -254,6 +254,30 @@ def test_kat8_knapsack_and_oracle_parity(gpu, oracle):
         assert r.Extra.astype(int).tolist() == ref.best_x.tolist()
 
 
+def test_knapsack_search_is_independent_of_the_speculation_width(gpu, oracle):
+    """The evaluated-leaves heap decides only WHEN a relaxation is computed, never what the search does with it: popped /
+    relaxations / expanded / largest heap / z / x equal the oracle's for every number of leaves expanded ahead per launch
+    (2 = nearly on demand ... 4096 = far ahead), with a node budget and to exhaustion."""
+    P, C_, S, R = gpu.LPProblem, gpu.Constraint, gpu.Sense, gpu.Rel
+    g = np.random.default_rng(91)
+    for n, cap_nodes in ((300, 0), (3000, 5000), (20000, 7000)):
+        w = g.integers(1, 1001, size=n).astype(float)
+        p = w + g.integers(0, 101, size=n)
+        cap = float(np.floor(0.5 * w.sum()))
+        ref = oracle.knapsack_solve(oracle.Problem(oracle.MAX, p, w.reshape(1, -1), [oracle.LE], [cap]), max_nodes=cap_nodes)
+        launches = []
+        for width in (2, 37, 256, 4096):
+            r = gpu.BranchAndBoundKnapsack(max_nodes=cap_nodes, concurrent_nodes=width).Solve(P(S.Max, p.tolist(), [C_(w.tolist(), R.LE, cap)]))
+            assert r.Nodes == ref.nodes_popped and r.Aux[0] == ref.relaxations and r.Aux[2] == ref.nodes_expanded, (n, width)
+            assert r.Aux[3] == ref.max_heap, (n, width)
+            if np.isfinite(ref.best_z):
+                assert r.OptimalValue == ref.best_z and r.Extra.astype(int).tolist() == ref.best_x.tolist(), (n, width)
+            launches.append(r.Stats["launches"])
+        assert launches[0] >= launches[2] >= launches[3]      # wider speculation = fewer, larger launches
+        if n >= 3000:
+            assert launches[0] > 2 * launches[2]
+
+
 @pytest.mark.parametrize("mode,key", [(0, "faithful"), (1, "repaired")])
 def test_kat9_bnb_revised(gpu, mode, key):
     """BranchAndBoundRevised -- node x*, z* re-parsed from the 3-decimal Summary text."""
@@ -328,10 +352,13 @@ def test_bnb_dive_policy_reaches_the_same_optimum(gpu, oracle, search):
         assert abs(np.asarray(r.Solution) @ c - ref.best_z) <= 1e-9 * abs(ref.best_z)
 
 
-def test_knapsack_device_node_store_expand_batch(gpu, oracle):
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_knapsack_device_node_store_expand_batch(gpu, oracle, monkeypatch, wide):
     """lpx_knapsack_expand_batch: nodes are derived on the device from a stored parent plus one decision; the stored lists
-    (ascending item index) and the three relaxations per job equal what lpx_knapsack_relax_batch2 / the oracle give for
-    the same fixed sets -- random chains 300+ deep (past the 256 register-cached entries), several generations per store."""
+    (returned in ascending item index) and the three relaxations per job equal what lpx_knapsack_relax_batch2 / the oracle
+    give for the same fixed sets -- random chains 560 deep: the wide kernel (64 probes per round, lists <= 512 decisions)
+    hands over to the one-probe-per-step kernel beyond its capacity; LPX_KNAP_WIDE=0 runs the latter throughout."""
+    monkeypatch.setenv("LPX_KNAP_WIDE", wide)
     g = np.random.default_rng(77)
     for n in (7, 60, 900, 5000):
         w = g.integers(1, 1001, size=n).astype(float)
@@ -341,7 +368,7 @@ def test_knapsack_device_node_store_expand_batch(gpu, oracle):
         order = oracle.knapsack_order(p, w)
         known = {-1: {}}                                   # id -> fixed dict
         frontier = [-1]
-        for gen in range(min(n - 1, 330)):
+        for gen in range(min(n - 1, 560 if wide == "1" else 300)):
             parents, items, vals = [], [], []
             for par in frontier[:6]:
                 free = [i for i in g.choice(n, size=min(n, 8), replace=False) if int(i) not in known[par]]
@@ -356,7 +383,7 @@ def test_knapsack_device_node_store_expand_batch(gpu, oracle):
                 fx = dict(known[par]); fx[it] = v
                 known[int(ids[j])] = fx
                 nodes.append(fx)
-                if gen % 40 == 0 or gen > 320:
+                if gen % 40 == 0 or gen > 540 or 505 < gen < 520:
                     assert dk.node_list(int(ids[j])) == fx, (n, gen, j)
                 if F[j, 0] >= 0:                           # stored children: node + fractional item fixed to 0 / 1
                     item2 = int(order[F[j, 0]])
