@@ -149,6 +149,9 @@ int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts
 int lpx_tableau_build_child(lpx_tableau* child, lpx_tableau* parent, int var, int row_of_var, int is_ge, double bound);
 int lpx_tableau_basis(lpx_tableau* t, int32_t* basis /* [R-1] */);
 int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32_t* basis_out /* [R-1] or NULL */);
+/* The same for a batch of solved nodes in ONE launch + one wait (the reads of FinalizeReport, Models/PrimalSimplex.cs:135-138,
+ * for every node of a branch-and-bound group): x is count x nvars, z has count entries, basis_out (or NULL) count x basis_stride. */
+int lpx_multi_solution(lpx_tableau** ts, int count, int nvars, double* x, double* z, int32_t* basis_out, int basis_stride);
 /* Parent store: a solved node parks its final tableau in a slab slot (one D2D copy) and gives its handle
  * back; its children are assembled from the slot.  Slots are sized for one capacity class (same Rcap/Ccap as
  * the handles that use the store) and allocated 32 at a time. */
@@ -157,6 +160,8 @@ int  lpx_store_create(int Rcap, int Ccap, lpx_store** out);
 void lpx_store_destroy(lpx_store* s);
 int  lpx_store_save(lpx_store* s, lpx_tableau* t, int* slot_out);
 int  lpx_store_release(lpx_store* s, int slot);
+/* The same for a batch of solved nodes (stores[i] / ts[i] / slots[i]): all copies are enqueued, then one wait per stream. */
+int  lpx_store_save_multi(lpx_store** stores, lpx_tableau** ts, int count, int* slots);
 int  lpx_tableau_build_child_from_store(lpx_tableau* child, lpx_store* s, int slot, int var, int row_of_var,
                                         int is_ge, double bound);
 

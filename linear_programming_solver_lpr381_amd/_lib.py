@@ -161,6 +161,8 @@ def lib() -> C.CDLL:
     L.lpx_store_destroy.restype = None
     L.lpx_store_save.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.lpx_store_release.argtypes = [vp, C.c_int]
+    L.lpx_store_save_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.lpx_multi_solution.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, dp, ip, C.c_int]
     L.lpx_tableau_build_child_from_store.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
     L.lpx_tableau_build_node.argtypes = [vp, vp, C.c_int, ip, dp, dp, dp]
     L.lpx_multi_run.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),

@@ -102,7 +102,31 @@ struct NodeLP {
     double wbound = 0.0; bool wis_ge = false; int wslot = 0; int depth = 0;
 };
 
+// index of the root constraints for the per-node feasibility test (IsFeasibleIndexed below)
+struct FeasIndex {
+    bool built = false; int n = 0;
+    std::vector<int> dense_rows; std::vector<double> ATd;          // [n][dense_rows.size()]
+    struct Sparse { int row; std::vector<std::pair<int, double>> nz; };
+    std::vector<Sparse> sparse;
+    void build(const LPProblem& root)
+    {
+        n = root.NumVars();
+        const int m = (int)root.Constraints.size();
+        for (int r = 0; r < m; ++r) {
+            const Constraint& c = root.Constraints[(size_t)r];
+            int nnz = 0; for (int i = 0; i < n; ++i) if (c.A[(size_t)i] != 0.0) ++nnz;
+            if (nnz * 8 > n) dense_rows.push_back(r);
+            else { Sparse s; s.row = r; for (int i = 0; i < n; ++i) if (c.A[(size_t)i] != 0.0) s.nz.emplace_back(i, c.A[(size_t)i]); sparse.push_back(std::move(s)); }
+        }
+        const size_t nd = dense_rows.size();
+        ATd.assign((size_t)n * nd, 0.0);
+        for (size_t d = 0; d < nd; ++d) { const Constraint& c = root.Constraints[(size_t)dense_rows[d]]; for (int i = 0; i < n; ++i) ATd[(size_t)i * nd + d] = c.A[(size_t)i]; }
+        built = true;
+    }
+};
+
 struct Ctx {
+    FeasIndex feas;
     const LPProblem* root; EngineOptions opt; UpdatePivot cb;
     double best = -INFINITY; bool has_best = false; std::vector<double> best_x;
     SimplexResult* out; HandlePool pool; bool stop = false;
@@ -172,6 +196,52 @@ bool IsFeasible(const std::vector<double>& x, const LPProblem& root, const std::
     for (const Cut& k : cuts) {
         double sum = 0;                                     // UnitVector row: 0*x_i terms add exact zeros
         for (size_t i = 0; i < x.size(); ++i) sum += ((int)i == k.var ? 1.0 : 0.0) * x[i];
+        if (k.rel == Rel::LE && sum > k.bound + EPS) return false;
+        if (k.rel == Rel::GE && sum < k.bound - EPS) return false;
+        if (k.rel == Rel::EQ && std::fabs(sum - k.bound) > EPS) return false;
+    }
+    for (double v : x) if (v < -EPS) return false;
+    return true;
+}
+
+// The same test with the work laid out for the host's caches: identical sums, hence identical verdicts.
+//  * a product with x_i == 0 is +-0 and leaves a running sum unchanged (the sums start at +0 and IEEE addition of a
+//    zero never changes a value; the sign of a zero sum plays no part in the comparisons), so zero entries are skipped;
+//  * rows with many coefficients are kept transposed ([variable][dense row]): the loop over the rows is contiguous and
+//    every row still accumulates its terms in ascending variable order, one rounded multiply and one rounded add each
+//    (the host code is built with -ffp-contract=off);
+//  * rows with a few coefficients (the x_j <= 1 rows of a binary program) keep a list of their non-zeros;
+//  * a branching row is a unit vector: its sum is x_k itself.
+// Non-finite values fall back to the plain loop (0 * inf is not a zero).
+bool row_ok(const Constraint& c, double sum)
+{
+    if (c.Relation == Rel::LE && sum > c.B + EPS) return false;
+    if (c.Relation == Rel::GE && sum < c.B - EPS) return false;
+    if (c.Relation == Rel::EQ && std::fabs(sum - c.B) > EPS) return false;
+    return true;
+}
+
+bool IsFeasibleIndexed(const std::vector<double>& x, const LPProblem& root, const std::vector<Cut>& cuts, FeasIndex& ix)
+{
+    if (!ix.built) ix.build(root);
+    for (double v : x) if (!std::isfinite(v)) return IsFeasible(x, root, cuts);
+    for (const Constraint& c : root.Constraints) if ((int)c.A.size() < ix.n) return IsFeasible(x, root, cuts);
+    const size_t nd = ix.dense_rows.size();
+    std::vector<double> sums(nd, 0.0);
+    for (int i = 0; i < ix.n && i < (int)x.size(); ++i) {
+        const double xi = x[(size_t)i];
+        if (xi == 0.0) continue;
+        const double* col = ix.ATd.data() + (size_t)i * nd;
+        for (size_t d = 0; d < nd; ++d) sums[d] += col[d] * xi;
+    }
+    for (size_t d = 0; d < nd; ++d) if (!row_ok(root.Constraints[(size_t)ix.dense_rows[d]], sums[d])) return false;
+    for (const FeasIndex::Sparse& s : ix.sparse) {
+        double sum = 0;
+        for (const auto& e : s.nz) if ((size_t)e.first < x.size()) sum += e.second * x[(size_t)e.first];
+        if (!row_ok(root.Constraints[(size_t)s.row], sum)) return false;
+    }
+    for (const Cut& k : cuts) {
+        const double sum = 0.0 + x[(size_t)k.var];
         if (k.rel == Rel::LE && sum > k.bound + EPS) return false;
         if (k.rel == Rel::GE && sum < k.bound - EPS) return false;
         if (k.rel == Rel::EQ && std::fabs(sum - k.bound) > EPS) return false;
@@ -276,30 +346,46 @@ void upload(Ctx& c, NodeLP& lp)
     std::vector<double>().swap(lp.T);
 }
 
-void collect(Ctx& c, NodeLP& lp, int status, const lpx_stats& st, int nvars)
+// Results of a whole batch: one launch + one wait reads every node's solution, the final tableaux that stay as
+// parents are parked with all their copies in flight together (a per-node form waits twice per node).
+void collect_group(Ctx& c, std::vector<NodeLP*>& live, const std::vector<int>& st, const std::vector<lpx_stats>& ss, int nvars)
 {
-    lp.pivots = st.pivots;
-    if (c.count_work) { c.out->Stats.pivots += st.pivots; c.out->Stats.launches += st.launches; c.out->Stats.loop_ms += st.loop_ms; }
-    if (status < 0) throw LpxException(status, "liblpx: " + last_error());
-    lp.status = status;
-    if (status == LPX_ITER_LIMIT) { lp.error = true; }              // exception in the reference
-    else if (lp.dual && c.opt.bnb_mode == 0) { lp.has_solution = false; }   // defect D2
-    else {
-        lp.x.assign(nvars, 0.0);
-        lp.basis_out.assign(std::max(lp.R - 1, 1), 0);
-        int rc = lpx_tableau_solution2(lp.h, nvars, lp.x.data(), &lp.z, lp.keep ? lp.basis_out.data() : nullptr);
+    std::vector<NodeLP*> want; std::vector<lpx_tableau*> hs; int maxm = 1;
+    for (size_t i = 0; i < live.size(); ++i) {
+        NodeLP& lp = *live[i];
+        lp.pivots = ss[i].pivots;
+        if (c.count_work) { c.out->Stats.pivots += ss[i].pivots; c.out->Stats.launches += ss[i].launches; c.out->Stats.loop_ms += ss[i].loop_ms; }
+        if (st[i] < 0) throw LpxException(st[i], "liblpx: " + last_error());
+        lp.status = st[i];
+        if (st[i] == LPX_ITER_LIMIT) lp.error = true;                    // exception in the reference
+        else if (lp.dual && c.opt.bnb_mode == 0) lp.has_solution = false;   // defect D2
+        else { want.push_back(&lp); hs.push_back(lp.h); maxm = std::max(maxm, lp.R - 1); }
+    }
+    if (!want.empty()) {
+        std::vector<double> xs((size_t)nvars * want.size()), zs(want.size());
+        std::vector<int32_t> bs((size_t)maxm * want.size());
+        int rc = lpx_multi_solution(hs.data(), (int)hs.size(), nvars, xs.data(), zs.data(), bs.data(), maxm);
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
-        lp.has_solution = true;
-        if (lp.keep && status == LPX_OPTIMAL) {          // park the final tableau for the children
-            lp.kstore = c.store_for(lp.h);
-            rc = lpx_store_save(lp.kstore, lp.h, &lp.kslot);
+        std::vector<lpx_store*> stores; std::vector<lpx_tableau*> keep_h; std::vector<NodeLP*> keep_lp;
+        for (size_t i = 0; i < want.size(); ++i) {
+            NodeLP& lp = *want[i];
+            lp.x.assign(xs.begin() + (size_t)i * nvars, xs.begin() + (size_t)(i + 1) * nvars);
+            lp.z = zs[i];
+            lp.basis_out.assign(std::max(lp.R - 1, 1), 0);
+            if (lp.keep && lp.R > 1) std::copy(bs.begin() + (size_t)i * maxm, bs.begin() + (size_t)i * maxm + (lp.R - 1), lp.basis_out.begin());
+            lp.has_solution = true;
+            if (lp.keep && lp.status == LPX_OPTIMAL) { stores.push_back(c.store_for(lp.h)); keep_h.push_back(lp.h); keep_lp.push_back(&lp); }
+        }
+        if (!keep_h.empty()) {                                           // park the final tableaux for the children
+            std::vector<int> slots(keep_h.size(), -1);
+            rc = lpx_store_save_multi(stores.data(), keep_h.data(), (int)keep_h.size(), slots.data());
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            for (size_t i = 0; i < keep_lp.size(); ++i) { keep_lp[i]->kstore = stores[i]; keep_lp[i]->kslot = slots[i]; }
         }
     }
-    c.pool.put(lp.h); lp.h = nullptr;
+    for (NodeLP* lp : live) { c.pool.put(lp->h); lp->h = nullptr; }
 }
 
-// solves a group of prepared relaxations, `concurrent_nodes` at a time (K9)
 void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
 {
     lpx_run_opts po, dopt; lpx_default_opts(&po, 0); lpx_default_opts(&dopt, 1);
@@ -343,7 +429,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         g_pt.run += PhaseTimer::now() - t0;
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         t0 = PhaseTimer::now();
-        for (size_t i = 0; i < live.size(); ++i) collect(c, *live[i], st[i], ss[i], nvars);
+        collect_group(c, live, st, ss, nvars);
         g_pt.collect += PhaseTimer::now() - t0;
     }
 }
@@ -381,7 +467,7 @@ int decide(Ctx& c, const std::vector<Cut>& cuts, const NodeLP& lp, int depth, co
     if (c.opt.bnb_mode == 1 && lp.status == LPX_INFEASIBLE) { node_log(c, depth, O_LP_INFEASIBLE, -1, lp.z); return -1; }
     const std::vector<double>& x = lp.x; const double z = lp.z;
     if (c.cb) c.log(name + " LP solution: z* = " + FormatF(z, 3));
-    if (!IsFeasible(x, *c.root, cuts)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
+    if (!IsFeasibleIndexed(x, *c.root, cuts, c.feas)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
     const double bestObj = c.has_best ? c.best : -INFINITY;
     // Sharded searches visit nodes level by level, not in the reference's depth-first order.  Among integer nodes with
     // EXACTLY the incumbent's z the one the reference's DFS reaches first keeps the solution vector (first found wins

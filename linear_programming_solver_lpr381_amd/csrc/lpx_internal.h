@@ -70,6 +70,8 @@ hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s);
 hipError_t launch_group_rhs_init(const SelParams* arr, int count, hipStream_t s);     // dual groups: contiguous RHS copy
 hipError_t launch_rhs_init(const SelParams& p, hipStream_t s);
 int update_blocks(int ld, int R);
+struct GatherDesc { const double* T; const int32_t* basis; int ld, R, C, off; };
+hipError_t launch_gather_solution(const GatherDesc* descs, int count, double* out_rhs, int32_t* out_basis, hipStream_t s);
 hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
                               int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s);
 hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* T, int ld, int R, int C,

@@ -458,7 +458,6 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
 {
-    __shared__ int s_out;
     __shared__ double s_v[MB_NT / 64];
     __shared__ int s_i[MB_NT / 64];
 
@@ -786,6 +785,26 @@ hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const i
 {
     hipLaunchKernelGGL(lpx_build_child, dim3((ld + 255) / 256, Rp + 1), dim3(256), 0, s, Tp, ldp, Rp, Cp, basis_p, T, ld,
                        var, ik, is_ge, bound, basis);
+    return hipGetLastError();
+}
+
+// Final solution of a whole batch of nodes in one launch (FinalizeReport's reads, Models/PrimalSimplex.cs:135-138, for
+// every node of a B&B group): block b copies node b's RHS column and basis into one contiguous record of the output,
+// which is pinned host memory the kernel writes directly -- one launch + one wait per batch instead of two strided
+// copies + one wait per node.
+__global__ __launch_bounds__(256) void lpx_gather_solution(const GatherDesc* __restrict__ descs, double* __restrict__ out_rhs,
+                                                           int32_t* __restrict__ out_basis)
+{
+    const GatherDesc D = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < D.R; i += 256) {
+        out_rhs[D.off + i] = D.T[(size_t)i * D.ld + (D.C - 1)];
+        if (i < D.R - 1) out_basis[D.off + i] = D.basis[i];
+    }
+}
+
+hipError_t launch_gather_solution(const GatherDesc* descs, int count, double* out_rhs, int32_t* out_basis, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_gather_solution, dim3(count), dim3(256), 0, s, descs, out_rhs, out_basis);
     return hipGetLastError();
 }
 

@@ -173,8 +173,6 @@ __global__ __launch_bounds__(256) void rv_ftran(RvParams P)
 __global__ __launch_bounds__(SEL_NT) void rv_select(RvParams P)
 {
     __shared__ int s_out;
-    __shared__ double s_v[SEL_NW];
-    __shared__ int s_i[SEL_NW];
     DevState* st = P.st;
     if (st->status != LPX_RUNNING) return;
     const int t = threadIdx.x;

@@ -1058,6 +1058,92 @@ int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32
     return 0;
 }
 
+// lpx_tableau_solution2 for a batch: x is count x nvars, z has count entries, basis_out (optional) count x basis_stride.
+int lpx_multi_solution(lpx_tableau** ts, int count, int nvars, double* x, double* z, int32_t* basis_out, int basis_stride)
+{
+    if (!ts || count < 0 || nvars < 0) { set_error("lpx_multi_solution: bad argument"); return LPX_EINVAL; }
+    if (count == 0) return 0;
+    struct Scratch { char* h = nullptr; size_t cap = 0; ~Scratch() { if (h) hipHostFree(h); } };
+    static thread_local Scratch sc;
+    size_t rows = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!ts[i] || ts[i]->R < 1) { set_error("lpx_multi_solution: null or empty tableau"); return LPX_EINVAL; }
+        if (basis_out && basis_stride < ts[i]->R - 1) { set_error("lpx_multi_solution: basis_stride too small"); return LPX_EINVAL; }
+        rows += (size_t)ts[i]->R;
+    }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_desc = 0, o_rhs = up16(sizeof(GatherDesc) * (size_t)count), o_bas = o_rhs + up16(sizeof(double) * rows);
+    const size_t need = o_bas + up16(sizeof(int32_t) * rows);
+    if (need > sc.cap) {
+        if (sc.h) hipHostFree(sc.h);
+        sc.h = nullptr; sc.cap = 0;
+        LPX_HIP_TRY(hipHostMalloc((void**)&sc.h, 2 * need));
+        sc.cap = 2 * need;
+    }
+    GatherDesc* d = reinterpret_cast<GatherDesc*>(sc.h + o_desc);
+    double* rhs = reinterpret_cast<double*>(sc.h + o_rhs);
+    int32_t* bas = reinterpret_cast<int32_t*>(sc.h + o_bas);
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        d[i].T = ts[i]->T; d[i].basis = ts[i]->basis; d[i].ld = ts[i]->ld; d[i].R = ts[i]->R; d[i].C = ts[i]->C; d[i].off = (int)off;
+        off += (size_t)ts[i]->R;
+    }
+    // every handle's own stream has to be idle before another stream reads its tableau
+    for (int i = 0; i < count; ++i) {
+        bool seen = false; for (int j = 0; j < i; ++j) if (ts[j]->stream == ts[i]->stream) { seen = true; break; }
+        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(ts[i]->stream));
+    }
+    hipStream_t s = ts[0]->stream;
+    LPX_HIP_TRY(launch_gather_solution(d, count, rhs, bas, s));
+    LPX_HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < count; ++i) {
+        const int m = ts[i]->R - 1;
+        const double* r = rhs + d[i].off; const int32_t* b = bas + d[i].off;
+        if (x) {
+            double* xi = x + (size_t)i * nvars;
+            for (int j = 0; j < nvars; ++j) xi[j] = 0.0;
+            for (int k = 0; k < m; ++k) if (b[k] >= 0 && b[k] < nvars) xi[b[k]] = r[k];       // FinalizeReport :135-136
+        }
+        if (z) z[i] = r[m];                                                                 // :138
+        if (basis_out && m > 0) std::memcpy(basis_out + (size_t)i * basis_stride, b, sizeof(int32_t) * m);
+    }
+    return 0;
+}
+
+// lpx_store_save for a batch: all copies are enqueued first, each stream is waited for once.
+int lpx_store_save_multi(lpx_store** ss, lpx_tableau** ts, int count, int* slots)
+{
+    if (!ss || !ts || !slots || count < 0) { set_error("lpx_store_save_multi: bad argument"); return LPX_EINVAL; }
+    for (int i = 0; i < count; ++i) {
+        lpx_store* s = ss[i]; lpx_tableau* t = ts[i];
+        if (!s || !t) { set_error("lpx_store_save_multi: null argument"); return LPX_EINVAL; }
+        if (t->ld != s->ld || t->R > s->Rcap) { set_error("lpx_store_save_multi: tableau does not match the store's capacity class"); return LPX_EINVAL; }
+    }
+    for (int i = 0; i < count; ++i) {
+        lpx_store* s = ss[i]; lpx_tableau* t = ts[i];
+        if (s->free_slots.empty()) {
+            double* Tc = nullptr; int32_t* bc = nullptr;
+            LPX_HIP_TRY(hipMalloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
+            hipError_t e = hipMalloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
+            if (e != hipSuccess) { hipFree(Tc); set_error("lpx_store_save_multi: out of device memory"); return LPX_ENOMEM; }
+            const int base = (int)s->chunks_T.size() * s->per_chunk;
+            s->chunks_T.push_back(Tc); s->chunks_b.push_back(bc);
+            s->R.resize(base + s->per_chunk, 0); s->C.resize(base + s->per_chunk, 0);
+            for (int k = s->per_chunk - 1; k >= 0; --k) s->free_slots.push_back(base + k);
+        }
+        const int slot = s->free_slots.back(); s->free_slots.pop_back();
+        LPX_HIP_TRY(hipMemcpyAsync(store_T(s, slot), t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, t->stream));
+        LPX_HIP_TRY(hipMemcpyAsync(store_b(s, slot), t->basis, sizeof(int32_t) * (t->R - 1), hipMemcpyDeviceToDevice, t->stream));
+        s->R[slot] = t->R; s->C[slot] = t->C;
+        slots[i] = slot;
+    }
+    for (int i = 0; i < count; ++i) {                                  // the handles may be reused, the slots read, right away
+        bool seen = false; for (int j = 0; j < i; ++j) if (ts[j]->stream == ts[i]->stream) { seen = true; break; }
+        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(ts[i]->stream));
+    }
+    return 0;
+}
+
 int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
                   const lpx_run_opts* dopts, int* statuses, lpx_stats* stats)
 {
