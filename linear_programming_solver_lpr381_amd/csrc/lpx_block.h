@@ -10,6 +10,10 @@ namespace lpx {
 static constexpr int SEL_NT = 1024;          // lanes of the single-workgroup select kernels
 static constexpr int SEL_NW = SEL_NT / 64;   // waves
 static constexpr int MB_NT = 256;            // lanes of one workgroup of the multi-workgroup select
+// words of the partial-index buffer behind its 128 entries, each on a 128-byte line of its own: the next entering column
+// reduced by the last select workgroup, and the arrival counter of the select workgroups
+static constexpr int MB_QREC = 128;
+static constexpr int MB_CNT = 160;
 static constexpr int MB_MAXB = 64;           // at most this many workgroups (partials fit one wave)
 
 // ------------------------------------------------------------------------------------------------

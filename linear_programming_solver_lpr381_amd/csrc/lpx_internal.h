@@ -41,6 +41,7 @@ struct SelParams {
     DevState* st;        // written by select (block 0), read by update and the host
     DevState* us;        // multi-workgroup select: written by update (block 0), read by select
     double* part_v; int32_t* part_i; int nblk;   // per-workgroup partial argmins of the lookahead scan
+    int qsel;                                    // 1: select's last workgroup reduces them (streaming update forms), 0: every update wave does
     double eps;          // Eps
     double tol_fdf;      // ratio hysteresis in phase 0
     double tol_dual;     // ratio hysteresis in phase 1
@@ -71,6 +72,7 @@ hipError_t launch_group_rhs_init(const SelParams* arr, int count, hipStream_t s)
 hipError_t launch_rhs_init(const SelParams& p, hipStream_t s);
 int update_blocks(int ld, int R);
 struct GatherDesc { const double* T; const int32_t* basis; int ld, R, C, off; };
+int update_policy(int ld, int R);            // 0 = cache-resident update kernel, 1 = all-nt streaming, 2 = mixed-store streaming
 hipError_t launch_gather_solution(const GatherDesc* descs, int count, double* out_rhs, int32_t* out_basis, hipStream_t s);
 hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
                               int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s);

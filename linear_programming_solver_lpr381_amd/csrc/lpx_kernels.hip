@@ -245,7 +245,7 @@ __device__ __forceinline__ void lpx_la_init_body(const SelParams& P)
     int qn = la_prepare_from_T(P, R, C, colc, scanrow, rule, s_v, s_i);
     if (threadIdx.x == 0) {
         st->qn = qn;
-        if (P.us) { *P.us = *st; P.us->qn = qn; }
+        if (P.us) { *P.us = *st; P.us->qn = qn; P.part_i[MB_CNT] = 0; }
     }
 }
 
@@ -360,6 +360,12 @@ static constexpr int UPD_ROWS = 8;
 static constexpr int UPDS_NT = 64;
 static constexpr int UPDS_ROWS = 3;
 static constexpr size_t UPD_STREAM_BYTES = (size_t)320 << 20;
+// UPDM: between the cache size and about twice it, storing ONE of the wave's three rows with the default policy (the other
+// two and all loads nontemporal) is worth another 6-8 %: a third of the tableau is then written through the Infinity
+// Cache and found there by the next pivot's loads.  Measured with the product's prologue (tools/kbench/sweep_dir.hip):
+// 4097 x 12289 (403 MB) 123.5 us all-nt -> 117.4 us, 5001 x 12001 (480 MB) the same ratio; at 576 MB the two forms meet,
+// from 784 MB on a third of the tableau no longer fits and the mixed form LOSES 12 % -- hence the upper bound.
+static constexpr size_t UPD_MIXED_BYTES = (size_t)512 << 20;
 
 typedef double lpx_d2 __attribute__((ext_vector_type(2)));
 // __builtin_nontemporal_load / _store lower to global_load_dwordx4 / global_store_dwordx4 ... nt on gfx950 and stay inside
@@ -383,7 +389,7 @@ template <bool STREAM> __device__ __forceinline__ void upd_store(double* p, doub
     }
 }
 
-template <int ROWS = UPD_ROWS, int NTH = UPD_NT, bool STREAM = false>
+template <int ROWS = UPD_ROWS, int NTH = UPD_NT, int POLICY = 0>
 __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
                                                 const int32_t* __restrict__ shape,
                                                 const double* __restrict__ prow,
@@ -412,16 +418,41 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
     const int row0 = rb * ROWS;
     if (row0 >= R) return;
     double* base = T + (size_t)row0 * ld + col;
+    constexpr bool NT = POLICY != 0;
+    const int c0 = cw * 128;
+    // straight-line path of almost every wave (see lpx_update_mb_body): all rows live, no pivot row, no column to capture
+    const bool plain_wave = row0 + ROWS <= R && (r < row0 || r >= row0 + ROWS) &&
+                            !(qn >= c0 && qn < c0 + 128) && !(rhsbuf != nullptr && C - 1 >= c0 && C - 1 < c0 + 128);
+    if (NT && plain_wave) {
+        double2 v[ROWS];
+        double f[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) v[k] = upd_load<NT>(base + (size_t)k * ld);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) f[k] = fac[row0 + k];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
+            v[k].y = v[k].y - f[k] * p.y;
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            if (POLICY == 2 && k == 0) upd_store<false>(base + (size_t)k * ld, v[k]);
+            else upd_store<NT>(base + (size_t)k * ld, v[k]);
+        }
+        return;
+    }
+    // every other wave -- and every wave of the cache-resident form (8 rows x 256 lanes, default policy), which measured
+    // FASTER with the per-row branches (lpx_update_b 53 vs 74 us, config 2's update 9.1 vs 16.4 us): all loads, then per row
     const bool wq = (qn >= 0) && ((qn & ~1) == col);              // this lane owns column qn
     const bool wr = (rhsbuf != nullptr) && (((C - 1) & ~1) == col);   // this lane owns the RHS column
-
     double2 v[ROWS];
     double f[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
-            v[k] = upd_load<STREAM>(base + (size_t)k * ld);
+            v[k] = upd_load<NT>(base + (size_t)k * ld);
             f[k] = fac[i];
         }
     }
@@ -432,7 +463,7 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
             double2 o;
             o.x = v[k].x - f[k] * p.x;          // mul, then sub: contraction is off
             o.y = v[k].y - f[k] * p.y;
-            upd_store<STREAM>(base + (size_t)k * ld, o);
+            upd_store<NT>(base + (size_t)k * ld, o);
             if (wq) nxt[i] = (qn & 1) ? o.y : o.x;
             if (wr) rhsbuf[i] = ((C - 1) & 1) ? o.y : o.x;
         }
@@ -447,14 +478,14 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
 // 4.6 us (in-kernel stamps, tools/diag_select_stamps.py).  Here `nblk` 256-lane workgroups run the
 // same step: every workgroup repeats the ratio test (contiguous 8 B x 2 x m, L2-resident, identical
 // result everywhere), then normalises ONE column slice of the pivot row, scans the same slice of the
-// updated objective row and publishes a partial argmin.  The update kernel reduces the <= 64 partials
-// in every wave (one load + 6 DPP steps) to learn the next entering column.
+// updated objective row and publishes a partial argmin; the workgroup that arrives last reduces the <= 128
+// partials to the next entering column (one word the update kernel reads).
 //
 // Two state records break what would otherwise be intra-kernel races:
 //   st  written by select workgroup 0, read by every update workgroup and by the host;
 //   us  written by update workgroup 0, read by every select workgroup.
-// Nothing is read and written by workgroups of the same launch, so no inter-workgroup fence is needed;
-// the kernel boundary orders the rest (placement-independent, cdna_hip_programming.md G16).
+// Apart from the partials (agent-scope stores and loads around one agent-scope counter, see below) nothing is read
+// and written by workgroups of the same launch; the kernel boundary orders the rest (cdna_hip_programming.md G16).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
 {
@@ -539,9 +570,53 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
         }
     }
     LPX_STAMP_MB(2);
-    best = wave_min_idx(best);                               // one partial per wave: no barrier, no LDS
+    best = wave_min_idx(best);                               // one partial per wave
     LPX_STAMP_MB(3);
-    if ((t & 63) == 0) { P.part_v[b * (MB_NT / 64) + (t >> 6)] = best.v; P.part_i[b * (MB_NT / 64) + (t >> 6)] = best.i; }
+    if (scanrow >= 0 && !P.qsel) {
+        if ((t & 63) == 0) { P.part_v[b * (MB_NT / 64) + (t >> 6)] = best.v; P.part_i[b * (MB_NT / 64) + (t >> 6)] = best.i; }
+    } else if (scanrow >= 0) {
+        // Streaming tableaux: the workgroup that arrives LAST reduces the partials to the next entering column, so that the update kernel's
+        // 10^5 waves read one word instead of each repeating a 128-entry reduction in front of their tile (that prologue
+        // cost the streaming update 10 % of its bandwidth, tools/kbench/sweep_dir.hip).  Hand-off as MI355X_MICROARCH.md
+        // prescribes for cross-XCD data without fences: every partial is an agent-scope (sc1) store, every storing wave
+        // waits for its stores, a workgroup barrier, ONE agent-scope add per workgroup; the workgroup whose add returns
+        // nblk - 1 loads the partials with agent-scope (sc1) loads, after its add has returned.
+        if ((t & 63) == 0) {
+            const int slot = b * (MB_NT / 64) + (t >> 6);
+            __hip_atomic_store(&P.part_v[slot], best.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P.part_i[slot], best.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < 64) {
+            int last = 0;
+            if (t == 0) last = (__hip_atomic_fetch_add(&P.part_i[MB_CNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.nblk - 1) ? 1 : 0;
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (last) {
+                MinIdx x; x.v = rule.forced ? 0.0 : __builtin_inf(); x.i = INT_MAX;
+                const int npart = P.nblk * (MB_NT / 64);               // <= 128
+                if (t < npart) {
+                    x.v = __hip_atomic_load(&P.part_v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x.i = __hip_atomic_load(&P.part_i[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (t + 64 < npart) {
+                    MinIdx y;
+                    y.v = __hip_atomic_load(&P.part_v[t + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y.i = __hip_atomic_load(&P.part_i[t + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x = mi_pick(x, y);
+                }
+                x = wave_min_idx(x);
+                int qn;
+                if (x.i == INT_MAX) qn = -1;
+                else if (rule.forced) { qn = rule.c0 + x.i; if (qn >= C) qn -= C; }
+                else qn = x.i;
+                if (t == 0) {
+                    P.part_i[MB_QREC] = qn;                                // read by the update kernel (next launch)
+                    __hip_atomic_store(&P.part_i[MB_CNT], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
     if (t == 0) {
         if (b == 0) {
             if (rule.forced) P.fchosen[k] = q; else P.basis[r] = q;     // basis[leaving] = entering, :110
@@ -560,7 +635,9 @@ __device__ __forceinline__ void lpx_select_mb_body(const SelParams& P)
 
 // lpx_update for the multi-workgroup protocol: same streaming body; the next entering column comes from
 // the select workgroups' partials, and workgroup 0 commits the state record `us` for the next select.
-template <int ROWS = UPD_ROWS, int NTH = UPD_NT, bool STREAM = false>
+// POLICY: 0 = default cache policy (tableau at home in the Infinity Cache), 1 = nontemporal loads and stores, 2 =
+// nontemporal loads, the wave's FIRST row stored with the default policy and the others nontemporal (see UPDM below).
+template <int ROWS = UPD_ROWS, int NTH = UPD_NT, int POLICY = 0>
 __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int ld, int Rcap, int Ccap,
                                                    const int32_t* __restrict__ shape,
                                                    const double* __restrict__ prow,
@@ -571,9 +648,9 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
                                                    const int32_t* __restrict__ part_i, int nblk,
                                                    int forced, int ncw, int nunits)
 {
+    constexpr bool NT = POLICY != 0;
     // The state record is read FIRST: a launch that finds the loop finished (tail of a batch, finished node
-    // of a B&B group) must not stream the tableau.  (Issuing the tile loads ahead of it was measured: no gain
-    // on live launches, a full 16*R*C of wasted traffic on every dead one.)
+    // of a B&B group) must not stream the tableau.
     const int status = st->status;
     const int r = st->r;
     const int lane = threadIdx.x & 63;
@@ -582,10 +659,16 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
         if (blockIdx.x == 0 && threadIdx.x == 0) { us->status = status; us->iter = st->iter; }
         return;
     }
-    // next entering column: override from select (skipped pivot / no scan row) or reduce the partials
+    // next entering column: set by select directly (skipped pivot / no scan row), or the minimum of the select workgroups'
+    // partials.  Streaming forms: the select workgroup that finished last has reduced them to one word (SelParams::qsel)
+    // -- 10^5 single-wave workgroups repeating the reduction in front of their tile cost the update 10 % of its bandwidth.
+    // Cache-resident form: every wave reduces them here (one load + 6 DPP steps), which is cheaper than the 1.5-2 us the
+    // last-workgroup hand-off adds to select when a pivot takes 15 us in all.
     int qn;
     if (st->qn_valid) {
         qn = st->qn;
+    } else if constexpr (POLICY != 0) {
+        qn = part_i[MB_QREC];
     } else {
         MinIdx x; x.v = forced ? 0.0 : __builtin_inf(); x.i = INT_MAX;
         const int npart = nblk * (MB_NT / 64);               // <= 128: one partial per select wave
@@ -615,16 +698,42 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
     if (row0 >= R) return;                                // capacity-sized grid: rows beyond the live shape
     const double2 p = *reinterpret_cast<const double2*>(prow + col);
     double* base = T + (size_t)row0 * ld + col;
+    const int c0 = cw * 128;
+    // Almost every wave takes the straight-line path: all ROWS rows live, none of them the pivot row, no column to
+    // capture.  Loads, arithmetic and stores follow each other without a branch, so the wait counts stay exact (with
+    // a branch per row the compiler waits for EVERYTHING, the previous row's store acknowledgement included, before
+    // each store).
+    const bool plain_wave = row0 + ROWS <= R && (r < row0 || r >= row0 + ROWS) &&
+                            !(qn >= c0 && qn < c0 + 128) && !(C - 1 >= c0 && C - 1 < c0 + 128);
+    if (NT && plain_wave) {
+        double2 v[ROWS];
+        double f[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) v[k] = upd_load<NT>(base + (size_t)k * ld);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) f[k] = fac[row0 + k];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
+            v[k].y = v[k].y - f[k] * p.y;
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            if (POLICY == 2 && k == 0) upd_store<false>(base + (size_t)k * ld, v[k]);
+            else upd_store<NT>(base + (size_t)k * ld, v[k]);
+        }
+        return;
+    }
+    // every other wave, and every wave of the cache-resident form (which measured faster with the per-row branches)
     const bool wq = (qn >= 0) && ((qn & ~1) == col);
     const bool wr = (((C - 1) & ~1) == col);
-
     double2 v[ROWS];
     double f[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int i = row0 + k;
         if (i < R) {
-            v[k] = upd_load<STREAM>(base + (size_t)k * ld);
+            v[k] = upd_load<NT>(base + (size_t)k * ld);
             f[k] = fac[i];
         }
     }
@@ -636,7 +745,7 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
             if (i != r) {
                 o.x = v[k].x - f[k] * p.x;      // mul, then sub: contraction is off
                 o.y = v[k].y - f[k] * p.y;
-                upd_store<STREAM>(base + (size_t)k * ld, o);
+                upd_store<NT>(base + (size_t)k * ld, o);
             } else {
                 o = p;                          // row r already holds the normalised pivot row
             }
@@ -688,14 +797,27 @@ __global__ __launch_bounds__(UPDS_NT) void lpx_update_s(double* T, int ld, int R
                                                         const double* prow, double* fac0, double* fac1, double* rhsbuf,
                                                         const DevState* st, int ncw, int nunits)
 {
-    lpx_update_body<UPDS_ROWS, UPDS_NT, true>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+    lpx_update_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+}
+__global__ __launch_bounds__(UPDS_NT) void lpx_update_m(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                        const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                        const DevState* st, int ncw, int nunits)
+{
+    lpx_update_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
 }
 __global__ __launch_bounds__(UPDS_NT) void lpx_update_mb_s(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
                                                            const double* prow, double* fac0, double* fac1, double* rhsbuf,
                                                            const DevState* st, DevState* us, const double* part_v,
                                                            const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
 {
-    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, true>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+}
+__global__ __launch_bounds__(UPDS_NT) void lpx_update_mb_m(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
+                                                           const double* prow, double* fac0, double* fac1, double* rhsbuf,
+                                                           const DevState* st, DevState* us, const double* part_v,
+                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
+{
+    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
 }
 // batched: every node of the group advances by one pivot per launch pair; grid.x covers the largest node
 __global__ __launch_bounds__(UPD_NT) void lpx_update_b(const SelParams* __restrict__ arr)
@@ -872,35 +994,29 @@ hipError_t launch_select_mb(const SelParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
-static bool update_streams(int ld, int R) { return sizeof(double) * (size_t)ld * (size_t)R > UPD_STREAM_BYTES; }
+// which streaming form a tableau of `bytes` takes: 0 = none (it lives in the Infinity Cache), 2 = mixed store policy, 1 = all nt
+int update_policy(int ld, int R)
+{
+    const size_t bytes = sizeof(double) * (size_t)ld * (size_t)R;
+    if (bytes <= UPD_STREAM_BYTES) return 0;
+    return bytes <= UPD_MIXED_BYTES ? 2 : 1;
+}
 
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
-    if (update_streams(p.ld, p.R)) {
-        const int ncw = (p.ld + 127) / 128, nunits = ncw * ((p.R + UPDS_ROWS - 1) / UPDS_ROWS);
-        const int nblocks = (nunits + (UPDS_NT / 64) - 1) / (UPDS_NT / 64);
-        const int forced = p.mode == MODE_FORCED ? 1 : 0;
-        if (e0 && e1)
-            hipExtLaunchKernelGGL(lpx_update_mb_s, dim3(nblocks), dim3(UPDS_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
-                                  (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
-                                  (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
-        else
-            hipLaunchKernelGGL(lpx_update_mb_s, dim3(nblocks), dim3(UPDS_NT), 0, s, p.T, p.ld, p.R, p.C, p.shape,
-                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
-                               (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
-        return hipGetLastError();
-    }
-    const int ncw = (p.ld + 127) / 128;
-    const int nrb = (p.R + UPD_ROWS - 1) / UPD_ROWS;
-    const int nunits = ncw * nrb;
-    const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
+    // the streaming forms read the entering column select's last workgroup reduced: both sides follow SelParams::qsel
+    const int pol = !p.qsel ? 0 : (update_policy(p.ld, p.R) == 2 ? 2 : 1);
+    const int rows = pol ? UPDS_ROWS : UPD_ROWS, nth = pol ? UPDS_NT : UPD_NT;
+    const int ncw = (p.ld + 127) / 128, nunits = ncw * ((p.R + rows - 1) / rows);
+    const int nblocks = (nunits + (nth / 64) - 1) / (nth / 64);
+    auto kern = pol == 0 ? lpx_update_mb : pol == 2 ? lpx_update_mb_m : lpx_update_mb_s;
     const int forced = p.mode == MODE_FORCED ? 1 : 0;
     if (e0 && e1)
-        hipExtLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
                               (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     else
-        hipLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(UPD_NT), 0, s, p.T, p.ld, p.R, p.C, p.shape,
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, p.T, p.ld, p.R, p.C, p.shape,
                            (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
                            (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
     return hipGetLastError();
@@ -949,27 +1065,15 @@ hipError_t launch_la_init(const SelParams& p, hipStream_t s)
 hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, const double* prow, double* fac0, double* fac1,
                          double* rhsbuf, const DevState* st, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
-    if (update_streams(ld, R)) {
-        const int ncw = (ld + 127) / 128, nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
-        const int nblocks = (nunits + (UPDS_NT / 64) - 1) / (UPDS_NT / 64);
-        if (e0 && e1)
-            hipExtLaunchKernelGGL(lpx_update_s, dim3(nblocks), dim3(UPDS_NT), 0, s, e0, e1, 0,
-                                  T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
-        else
-            hipLaunchKernelGGL(lpx_update_s, dim3(nblocks), dim3(UPDS_NT), 0, s,
-                               T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
-        return hipGetLastError();
-    }
-    const int ncw = (ld + 127) / 128;
-    const int nrb = (R + UPD_ROWS - 1) / UPD_ROWS;
-    const int nunits = ncw * nrb;
-    const int nblocks = (nunits + (UPD_NT / 64) - 1) / (UPD_NT / 64);
+    const int pol = update_policy(ld, R);
+    const int rows = pol ? UPDS_ROWS : UPD_ROWS, nth = pol ? UPDS_NT : UPD_NT;
+    const int ncw = (ld + 127) / 128, nunits = ncw * ((R + rows - 1) / rows);
+    const int nblocks = (nunits + (nth / 64) - 1) / (nth / 64);
+    auto kern = pol == 0 ? lpx_update : pol == 2 ? lpx_update_m : lpx_update_s;
     if (e0 && e1)
-        hipExtLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s, e0, e1, 0,
-                              T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
     else
-        hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(UPD_NT), 0, s,
-                           T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
     return hipGetLastError();
 }
 

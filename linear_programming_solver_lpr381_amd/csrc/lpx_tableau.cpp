@@ -128,7 +128,7 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
     const size_t nb = R > 1 ? (size_t)R - 1 : 1;
     const size_t sz[] = { up(sizeof(double) * t->ld), up(sizeof(double) * R), up(sizeof(double) * R), up(sizeof(double) * R),
                           up(sizeof(double) * R), up(sizeof(double) * (size_t)wsn * 32), up(sizeof(double) * 192),
-                          up(sizeof(int32_t) * 128), up(sizeof(DevState)), up(sizeof(int32_t) * nb),
+                          up(sizeof(int32_t) * 256), up(sizeof(DevState)), up(sizeof(int32_t) * nb),
                           up(sizeof(int32_t) * 2 * (size_t)t->trace_cap), up(sizeof(DevState)), up(sizeof(int32_t) * 2) };
     size_t total = 0;
     for (size_t b : sz) total += b;
@@ -367,7 +367,7 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
     p.rcap = 0;
     static const bool mb_env = [] { const char* e = std::getenv("LPX_SELECT_MB"); return !(e && e[0] == '0'); }();
     if (mode != MODE_DUAL && mb_env && t->use_mb) {
-        p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->Ccap);
+        p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->Ccap); p.qsel = update_policy(t->ld, t->Rcap) != 0 ? 1 : 0;
     }
     return p;
 }
