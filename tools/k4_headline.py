@@ -34,3 +34,9 @@ rv = L.DeviceRevised(A3, -c3, b3)
 status, st = rv.run(max_iter=npiv, batch=20, use_graph=0)
 print("revised iterations", st["pivots"], "status", status)
 rv.close()
+del A3
+# config 5: the knapsack expansion kernel (bytes per bound: per-launch traffic / (grid / 64 jobs x 3 bounds))
+pk, wk, capk = synth.knapsack(100_000)
+kp = L.LPProblem(L.Sense.Max, pk.tolist(), [L.Constraint(wk.tolist(), L.Rel.LE, capk)])
+rk = L.BranchAndBoundKnapsack(max_nodes=20000, concurrent_nodes=512).Solve(kp)
+print("knapsack pops", rk.Nodes, "launches", rk.Stats["launches"])
