@@ -5,6 +5,9 @@
 //   head  [0, a)      lines expected in the cache (written last by the previous sweep): loads default, stores nt
 //   body  [a, 1 - a)  streams through: loads nt, stores nt
 //   tail  [1 - a, 1)  to be kept for the next sweep: loads nt, stores default
+// (*) CAUTION about the `upd` switch kernel: the compiler merges the tails of its mode blocks, so the store policy of a row
+// is not always what the source says for that mode (its third store comes out with the default policy).  That is how the
+// store mix was found; upd_exp / upd_mask / upd_cand are the controlled forms and the ones the product kernel follows.
 // hipcc --offload-arch=gfx950 -O3 -ffp-contract=off sweep_dir.hip -o sweep_dir ; ./sweep_dir [R C reps]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -423,7 +426,7 @@ int main(int argc, char** argv)
     printf("R=%d C=%d ld=%d  tableau %.1f MB, algorithmic bytes per launch %.1f MB, %d units\n", R, C, ld, tab_mb, bytes / 1e6, total);
     struct V { std::string name; int mode; bool alt; double head_mb, tail_mb; };
     std::vector<V> vs = {
-        {"nt/nt one direction (the product kernel)", 0, false, 0, 0},
+        {"switch kernel, mode nt/nt, one direction (*)", 0, false, 0, 0},
         {"nt/nt alternating", 0, true, 0, 0},
         {"default/default one direction", 1, false, 0, 0},
         {"default/default alternating", 1, true, 0, 0},
