@@ -30,10 +30,12 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-@pytest.mark.parametrize("R,C,count", [(4096, 8192, 12), (4097, 12289, 8)])
+@pytest.mark.parametrize("R,C,count", [(4096, 8192, 12), (4097, 12289, 8), (4097, 17001, 6)])
 def test_forced_pivots_bitwise_at_headline_shapes(gpu, oracle, R, C, count):
-    """K4 lpx_update_mb on the shapes the roofline is quoted on: every element of the tableau after `count`
-    pivots equals the oracle's (uint64 view), and so does every chosen pivot column."""
+    """K4 on the shapes the roofline is quoted on and on one of every update form (256 MiB: lpx_update_mb, cache policy
+    default; 403 MB: lpx_update_mb_m, one row in three stored through the Infinity Cache; 557 MB: lpx_update_mb_s, all
+    non-temporal -- the last two with the entering column reduced by select's last workgroup): every element of the tableau
+    after `count` pivots equals the oracle's (uint64 view), and so does every chosen pivot column."""
     T0 = synth.raw_tableau(R, C)
     rows, cols = synth.forced_pivot_list(R, C, count)
     Tr = T0.copy()
@@ -47,18 +49,19 @@ def test_forced_pivots_bitwise_at_headline_shapes(gpu, oracle, R, C, count):
 
 def test_primal_solve_first_pivots_of_the_4096x8192_lp(gpu, oracle):
     """The LP bench.py's headline value is measured on (m=4096, n=8192, tableau 4097x12289 = 403 MB, streaming
-    kernels lpx_select_mb + lpx_update_mb): first 40 pivots, trace / basis / whole tableau bit-equal."""
+    kernels lpx_select_mb + lpx_update_mb_m): first 150 pivots -- three hipGraph batches, so the hand-off of the entering
+    column from select's last workgroup to the update kernel crosses replays -- trace / basis / whole tableau bit-equal."""
     c, A, b = synth.dense_lp(4096, 8192)
     T, basis = synth.primal_tableau_from(c, A, b)
     del A
     Tr, br = T.copy(), basis.copy()
-    st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=40)
+    st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=150)
     with gpu.DeviceTableau.from_host(T, basis) as dt:
-        status, st = dt.primal_run(max_iter=40)
-        assert st["launches"] > 40                      # streaming path: two launches per pivot, not one resident launch
+        status, st = dt.primal_run(max_iter=150)
+        assert st["launches"] > 150                     # streaming path: two launches per pivot, not one resident launch
         tr = dt.trace()
         Tg, bg = dt.download()
-    assert status == st_ref == 3 and len(tr_ref) == 40
+    assert status == st_ref == 3 and len(tr_ref) == 150
     assert tr.tolist() == tr_ref.tolist() and bg.tolist() == br.tolist()
     assert np.array_equal(_bits(Tg), _bits(Tr))
 
