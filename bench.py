@@ -273,6 +273,20 @@ def main():
                                       f"loop only) -- an engine mode, not the reference's algorithm; GLOBAL budget {args.bnb_warm_nodes} nodes, "
                                       f"{args.bnb_warm_concurrent} node LPs per batch",
                                   bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent, max_nodes=args.bnb_warm_nodes)
+        # what the node evaluation of config 4 amounts to in the path's unit (16*R*C bytes per pivot); the root
+        # tableau's shape is a lower bound of every node's (a node at depth d has d more rows and columns)
+        R0, C0 = 256 + 512 + 1, 512 + 256 + 512 + 1
+        for key, note in (("bnb", "the node tableaux live in LDS (lpx_resident_group, four nodes at a time): this is the rate a streaming "
+                                  "implementation would have to sustain, not HBM traffic; the kernel is bound by its per-pivot exchange "
+                                  "latency (9.4 us per pivot step of four nodes)"),
+                          ("bnb_warm", "batched streaming kernels lpx_select_b + lpx_update_b (HBM-bound; a batch runs as long as its "
+                                       "slowest node, on average 19 of 64 nodes are still active per step)")):
+            leg = out[key]
+            rate = leg["pivots"] * 16.0 * R0 * C0 / leg["wall_s"] / 1e9
+            leg["roofline"] = {"bound": "latency" if key == "bnb" else "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                               "achieved": rate, "frac": rate / HBM_PEAK_GBS,
+                               "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
+                               "note": note}
         # ---- a 0/1 IP small enough to be SOLVED: incumbents appear, the all-reduced bound prunes, pools are rebalanced ----
         cs, As, rels, bs = synth.binary_ip(args.bnb_prune_n, args.bnb_prune_m)
         ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)
@@ -300,6 +314,16 @@ def main():
                            "bound": "host replay of the reference's pop order (sequential by definition: popped/expanded/"
                                     "relaxations must equal the reference's); the device evaluates the 512 best evaluated "
                                     "leaves ahead of the search per launch (3 relaxations per job, ~1000 jobs per launch)"}
+        pmc, pmc_src = committed_profile("pmc_traffic.json")
+        if pmc:
+            full = [(k, v) for k, v in pmc.items() if "knap_expand_w@grid" in k]
+            if full:
+                k_, v_ = max(full, key=lambda kv: kv[1]["launches_fetch"])
+                jobs = int(k_.split("@grid")[1]) // 64
+                out["knapsack"]["kernel"] = {"name": "knap_expand_w", "jobs_per_launch": jobs,
+                                             "hbm_bytes_per_bound": v_["hbm_bytes_per_launch"] / (3.0 * jobs),
+                                             "full_scan_bytes_per_bound": 16.0 * 100_000,
+                                             "source": f"{pmc_src} (committed PMC passes, FETCH x2 + WRITE; not a measurement of this run)"}
 
     if rank == 0 and not args.no_extras:
         progress("roofline legs")
