@@ -37,10 +37,10 @@ struct Cut { int var; Rel rel; double bound; };
 
 // LPX_BNB_TIMING=1: print where the host spends its time (diagnostic)
 struct PhaseTimer {
-    double build = 0, run = 0, collect = 0, decide = 0, root = 0, total = 0; bool on = false;
+    double build = 0, run = 0, collect = 0, decide = 0, root = 0, total = 0, readback = 0, parking = 0; bool on = false;
     PhaseTimer() { const char* e = std::getenv("LPX_BNB_TIMING"); on = e && e[0] == '1'; }
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] root %.1f ms, build %.1f ms, run %.1f ms, collect %.1f ms, decide %.1f ms, whole solves %.1f ms\n", root, build, run, collect, decide, total); }
+    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] root %.1f ms, build %.1f ms, run %.1f ms, collect %.1f ms (read-back %.1f, parking %.1f), decide %.1f ms, whole solves %.1f ms\n", root, build, run, collect, readback, parking, decide, total); }
 };
 static PhaseTimer g_pt;
 
@@ -364,7 +364,9 @@ void collect_group(Ctx& c, std::vector<NodeLP*>& live, const std::vector<int>& s
     if (!want.empty()) {
         std::vector<double> xs((size_t)nvars * want.size()), zs(want.size());
         std::vector<int32_t> bs((size_t)maxm * want.size());
+        double t0 = PhaseTimer::now();
         int rc = lpx_multi_solution(hs.data(), (int)hs.size(), nvars, xs.data(), zs.data(), bs.data(), maxm);
+        g_pt.readback += PhaseTimer::now() - t0;
         if (rc) throw LpxException(rc, "liblpx: " + last_error());
         std::vector<lpx_store*> stores; std::vector<lpx_tableau*> keep_h; std::vector<NodeLP*> keep_lp;
         for (size_t i = 0; i < want.size(); ++i) {
@@ -378,7 +380,9 @@ void collect_group(Ctx& c, std::vector<NodeLP*>& live, const std::vector<int>& s
         }
         if (!keep_h.empty()) {                                           // park the final tableaux for the children
             std::vector<int> slots(keep_h.size(), -1);
+            t0 = PhaseTimer::now();
             rc = lpx_store_save_multi(stores.data(), keep_h.data(), (int)keep_h.size(), slots.data());
+            g_pt.parking += PhaseTimer::now() - t0;
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
             for (size_t i = 0; i < keep_lp.size(); ++i) { keep_lp[i]->kstore = stores[i]; keep_lp[i]->kslot = slots[i]; }
         }

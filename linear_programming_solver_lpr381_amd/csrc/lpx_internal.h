@@ -88,6 +88,7 @@ struct ResNode {
     double* T; int ld, R, C;
     int32_t* basis; int32_t* trace; int trace_cap;
     DevState* st;
+    DevState* st_host;       // pinned host mirror of the fields the launch changes (the host reads it instead of copying `st` back)
     unsigned long long* xr;  // [2][mcap][2][2]  (a, rhs) granule pairs per row
     unsigned long long* xp;  // [2][ld+8][2]     pivot row granules, then the header {q}
     unsigned* xgen;

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     }
 
     if (hung) {
-        if (t == 0) atomicOr(&st->pad[1], 1);
+        if (t == 0) { atomicOr(&st->pad[1], 1); if (N.st_host) N.st_host->pad[1] = 1; }
         return;
     }
     for (int i = 0; i < nloc; ++i) {
@@ -322,6 +322,11 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             st->status = status; st->iter = iter; st->phase = phase;
             st->fdf_count = fdf_count; st->dual_iter = dual_iter; st->primal_count = primal_count;
             st->r = status == LPX_RUNNING ? r : -1; st->q = status == LPX_RUNNING ? qlast : -1;
+            if (DevState* hm = N.st_host) {              // the same fields, straight into the host's pinned copy
+                hm->status = status; hm->iter = iter; hm->phase = phase;
+                hm->fdf_count = fdf_count; hm->dual_iter = dual_iter; hm->primal_count = primal_count;
+                hm->r = status == LPX_RUNNING ? r : -1; hm->q = status == LPX_RUNNING ? qlast : -1;
+            }
             *N.xgen = gen;
         }
     }

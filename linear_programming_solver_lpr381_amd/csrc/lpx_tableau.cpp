@@ -554,6 +554,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         DevState init; std::memset(&init, 0, sizeof(init));
         init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = dual[i] ? 0 : 2;
         g.hs[i] = init;
+        n.st_host = &g.hs[i];
         LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[i], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
     }
     // launch length: long enough to hide the launch + reload (~30 us), short enough that a node finishing inside a
@@ -565,20 +566,28 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     for (int i = 0; i < count; ++i) live[i] = i;
     std::vector<int> fired(count, 0);
     std::vector<DevState> before(count);
+    std::vector<char> snapped(count, 0);
+    // What an aborted launch goes back to: with a pivot callback the state at the START OF THAT LAUNCH (the callbacks of the
+    // earlier launches have fired), snapshot per launch; without one (B&B batches) the node's state at its FIRST launch --
+    // one snapshot per node instead of one per launch (a node of config 4 takes eight launches), the rare restart repeats
+    // the node's pivots on the streaming kernels and ends in the same tableau.
+    const bool snap_each_launch = cb != nullptr;
     long long launches = 0;
     while (!live.empty()) {
         const int n = (int)live.size() < slots ? (int)live.size() : slots;
         for (int k = 0; k < n; ++k) {
             g.h[k] = node[live[k]];
-            lpx_tableau* t = ts[live[k]];          // tableau, basis and state as of the start of this launch (put back if it aborts)
-            before[live[k]] = g.hs[live[k]];
-            LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
-            LPX_HIP_TRY(hipMemcpyAsync(t->xT, t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, g.stream));
+            lpx_tableau* t = ts[live[k]];
+            if (snap_each_launch || !snapped[live[k]]) {
+                before[live[k]] = g.hs[live[k]];
+                LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
+                LPX_HIP_TRY(hipMemcpyAsync(t->xT, t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, g.stream));
+                snapped[live[k]] = 1;
+            }
         }
+        // the kernel writes each node's new state into the pinned mirror (ResNode::st_host): nothing is copied back
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
         LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
-        for (int k = 0; k < n; ++k)
-            LPX_HIP_TRY(hipMemcpyAsync(&g.hs[live[k]], ts[live[k]]->st, sizeof(DevState), hipMemcpyDeviceToHost, g.stream));
         LPX_HIP_TRY(hipStreamSynchronize(g.stream));
         bool aborted = false;
         for (int k = 0; k < n; ++k) if (g.hs[live[k]].pad[1]) aborted = true;
@@ -595,6 +604,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
                 LPX_HIP_TRY(hipMemcpy(t->basis, t->xbasis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice));
                 g.hs[live[k]] = before[live[k]];
                 g.hs[live[k]].pad[1] = 0;
+                LPX_HIP_TRY(hipMemcpy(t->st, &g.hs[live[k]], sizeof(DevState), hipMemcpyHostToDevice));
             }
             for (int i = 0; i < count; ++i) statuses[i] = g.hs[i].status;      // LPX_RUNNING marks the unfinished ones
             if (resume) std::memcpy(resume, g.hs, sizeof(DevState) * count);
