@@ -436,3 +436,59 @@ def test_knapsack_solve_same_counts_with_and_without_the_device_store(oracle):
     import json
     got = json.loads(outs[0])
     assert got[0] == ref.nodes_popped and got[1] == ref.relaxations and got[2] == ref.nodes_expanded
+
+
+def test_batched_solution_readback_and_parking_equal_the_per_node_calls(gpu):
+    """lpx_multi_solution / lpx_store_save_multi (the B&B group's read-back and parent parking in one launch / one wait)
+    against lpx_tableau_solution2 / lpx_store_save node by node: x, z, basis equal; a child built from a slot parked by
+    either call is the same tableau, bit for bit."""
+    import ctypes as C
+    lib = gpu._lib.lib()
+    g = np.random.default_rng(5)
+    m, n, count = 37, 21, 6
+    R, Cc = m + 1, n + m + 1
+    ts = []
+    for k in range(count):
+        A = g.random((m, n)); b = 0.5 * n * g.uniform(0.9, 1.1, m); c = g.uniform(0.5, 1.5, n)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        t = gpu.DeviceTableau(R + 1, Cc + 1)            # capacity for one more row / column: the warm-start child
+        gpu._lib.check(lib.lpx_tableau_set_shape(t._h, R, Cc))
+        t.R, t.C = R, Cc
+        t.upload(T, basis)
+        status, _ = t.primal_run()
+        assert status == 0
+        ts.append(t)
+    arr = (C.c_void_p * count)(*[t._h for t in ts])
+    x = np.zeros((count, n)); z = np.zeros(count); bs = -np.ones((count, m + 3), np.int32)
+    gpu._lib.check(lib.lpx_multi_solution(arr, count, n, x.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double)),
+                                          bs.ctypes.data_as(C.POINTER(C.c_int32)), m + 3))
+    for k, t in enumerate(ts):
+        x1 = np.zeros(n); z1 = C.c_double(); b1 = np.zeros(m, np.int32)
+        gpu._lib.check(lib.lpx_tableau_solution2(t._h, n, x1.ctypes.data_as(C.POINTER(C.c_double)), C.byref(z1), b1.ctypes.data_as(C.POINTER(C.c_int32))))
+        assert np.array_equal(x[k].view(np.uint64), x1.view(np.uint64)) and z[k] == z1.value
+        assert bs[k, :m].tolist() == b1.tolist() and bs[k, m:].tolist() == [-1, -1, -1]
+    store = C.c_void_p()
+    gpu._lib.check(lib.lpx_store_create(R + 1, Cc + 1, C.byref(store)))
+    try:
+        slots = (C.c_int * count)()
+        stores = (C.c_void_p * count)(*[store] * count)
+        gpu._lib.check(lib.lpx_store_save_multi(stores, arr, count, slots))
+        assert len(set(slots)) == count
+        for k, t in enumerate(ts):
+            one = C.c_int(-1)
+            gpu._lib.check(lib.lpx_store_save(store, t._h, C.byref(one)))
+            assert one.value not in list(slots)
+            # the branching variable: any basic structural variable of this node
+            T0, b0 = t.download()
+            row = next(i for i in range(m) if b0[i] < n)
+            kids = []
+            for slot in (slots[k], one.value):
+                ch = gpu.DeviceTableau(R + 1, Cc + 1)
+                gpu._lib.check(lib.lpx_tableau_build_child_from_store(ch._h, store, slot, int(b0[row]), row, 0, float(np.floor(T0[row, -1]))))
+                ch.R, ch.C = R + 1, Cc + 1
+                kids.append(ch.download()); ch.close()
+            assert np.array_equal(kids[0][0].view(np.uint64), kids[1][0].view(np.uint64)) and kids[0][1].tolist() == kids[1][1].tolist()
+    finally:
+        lib.lpx_store_destroy(store)
+        for t in ts:
+            t.close()
