@@ -78,6 +78,8 @@ struct Heap {                                              // SimpleMaxHeap<Node
         size_t i = 0;
         for (;;) {
             size_t l = 2 * i + 1, r = 2 * i + 2, largest = i;
+            // the four grandchildren are 64 contiguous bytes: have them on their way while this level is compared
+            if (4 * i + 3 <= li) __builtin_prefetch(&d[4 * i + 3]);
             if (l <= li && cmp(d[l], d[largest]) > 0) largest = l;
             if (r <= li && cmp(d[r], d[largest]) > 0) largest = r;
             if (largest == i) break;
