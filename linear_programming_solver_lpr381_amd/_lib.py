@@ -177,6 +177,8 @@ def lib() -> C.CDLL:
     L.lpx_test_set_seams.restype = None
     L.lpx_knapsack_expand_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int8), C.POINTER(C.c_int64),
                                             dp, dp, ip, dp]
+    L.lpx_knapsack_expand_begin.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int8), C.POINTER(C.c_int64)]
+    L.lpx_knapsack_expand_finish.argtypes = [vp, dp, dp, ip, dp]
     L.lpx_knapsack_node_list.argtypes = [vp, C.c_int64, ip, C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_int)]
     L.lpx_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
     L.lpx_default_solve_opts.restype = None

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -127,40 +128,15 @@ struct Search {
 
     // one launch: child `v` of every job's node (its fractional item fixed to v) and, with depth2, that child's two children
     struct Job { KNode* node; int v; };
-    void run_jobs(std::vector<Job>& jobs)
+    // a batch in flight on the device (store path): its jobs and the ids the device gave the new nodes
+    std::vector<Job> flying; std::vector<int64_t> flying_ids;
+    bool in_flight() const { return !flying.empty(); }
+    int64_t n_async = 0, n_sync = 0, n_async_hit = 0; double wait_ms = 0, begin_ms = 0;   // diagnostics (LPX_KNAP_DEBUG=1)
+
+    void integrate(const std::vector<Job>& jobs, const std::vector<int64_t>& ch, const std::vector<double>& p, const std::vector<double>& w,
+                   const std::vector<int32_t>& fr, const std::vector<double>& fv)
     {
-        if (jobs.empty()) return;
-        const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
-        std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
-        std::vector<int64_t> ch(jobs.size(), -1);
-        if (use_store) {
-            // 48 bytes per job: (parent id, item, value); the device derives, stores and evaluates the child
-            std::vector<int64_t> par(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
-            for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = order[jobs[j].node->self.frac]; vv[j] = (int8_t)jobs[j].v; }
-            int rc;
-            { Clock c(dev_ms);
-              rc = lpx_knapsack_expand_batch(k, (int)jobs.size(), par.data(), it.data(), vv.data(), ch.data(), p.data(), w.data(), fr.data(), fv.data()); }
-            if (rc) throw LpxException(rc, "liblpx: " + last_error());
-        } else {
-            std::vector<int32_t> off(jobs.size() + 1, 0), fidx, li; std::vector<int8_t> fval, lv;
-            for (size_t j = 0; j < jobs.size(); ++j) {
-                jobs[j].node->list(li, lv);                  // ascending index order (:442)
-                const int it = order[jobs[j].node->self.frac];
-                bool placed = false;
-                for (size_t e = 0; e < li.size(); ++e) {
-                    if (!placed && it < li[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
-                    fidx.push_back(li[e]); fval.push_back(lv[e]);
-                }
-                if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
-                off[j + 1] = (int32_t)fidx.size();
-            }
-            int rc;
-            { Clock c(dev_ms);
-              rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                 : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
-                          : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data()); }
-            if (rc) throw LpxException(rc, "liblpx: " + last_error());
-        }
+        const size_t st = depth2 ? 3 : 1;
         ++launches; jobs_run += (int64_t)jobs.size();
         auto fill = [&](KNode* x, KNode* parent, int item, int v, size_t o, int64_t dev) {
             x->parent = parent; x->item = item; x->val = (int8_t)v; x->depth = parent->depth + 1; x->dev = dev;
@@ -183,6 +159,71 @@ struct Search {
                 }
             } else if (!depth2) offer_leaf(c);
         }
+    }
+
+    // store path, asynchronous half: enqueue the batch and return -- the device works while the host replays the search
+    void begin_jobs(std::vector<Job>& jobs)
+    {
+        std::vector<int64_t> par(jobs.size()); std::vector<int32_t> it(jobs.size()); std::vector<int8_t> vv(jobs.size());
+        for (size_t j = 0; j < jobs.size(); ++j) { par[j] = jobs[j].node->dev; it[j] = order[jobs[j].node->self.frac]; vv[j] = (int8_t)jobs[j].v; }
+        flying_ids.assign(jobs.size(), -1);
+        int rc;
+        { Clock c(dev_ms); Clock c2(begin_ms); rc = lpx_knapsack_expand_begin(k, (int)jobs.size(), par.data(), it.data(), vv.data(), flying_ids.data()); }
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        flying.swap(jobs);
+    }
+    void finish_jobs()
+    {
+        if (flying.empty()) return;
+        const size_t nout = 3 * flying.size();
+        std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
+        int rc;
+        { Clock c(dev_ms); Clock c2(wait_ms); rc = lpx_knapsack_expand_finish(k, p.data(), w.data(), fr.data(), fv.data()); }
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        std::vector<Job> jobs; jobs.swap(flying);
+        integrate(jobs, flying_ids, p, w, fr, fv);
+    }
+
+    void run_jobs(std::vector<Job>& jobs)
+    {
+        if (jobs.empty()) return;
+        if (use_store) { begin_jobs(jobs); finish_jobs(); return; }
+        const size_t st = depth2 ? 3 : 1, nout = st * jobs.size();
+        std::vector<double> p(nout), w(nout), fv(nout); std::vector<int32_t> fr(nout);
+        std::vector<int64_t> ch(jobs.size(), -1);
+        std::vector<int32_t> off(jobs.size() + 1, 0), fidx, li; std::vector<int8_t> fval, lv;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            jobs[j].node->list(li, lv);                  // ascending index order (:442)
+            const int it = order[jobs[j].node->self.frac];
+            bool placed = false;
+            for (size_t e = 0; e < li.size(); ++e) {
+                if (!placed && it < li[e]) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); placed = true; }
+                fidx.push_back(li[e]); fval.push_back(lv[e]);
+            }
+            if (!placed) { fidx.push_back(it); fval.push_back((int8_t)jobs[j].v); }
+            off[j + 1] = (int32_t)fidx.size();
+        }
+        int rc;
+        { Clock c(dev_ms);
+          rc = test_relax ? test_relax((int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+             : depth2 ? lpx_knapsack_relax_batch2(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data())
+                      : lpx_knapsack_relax_batch(k, (int)jobs.size(), off.data(), fidx.data(), fval.data(), p.data(), w.data(), fr.data(), fv.data()); }
+        if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        integrate(jobs, ch, p, w, fr, fv);
+    }
+
+    // the best evaluated leaves, two jobs each
+    int take_leaves(std::vector<Job>& jobs, int want)
+    {
+        int taken = 0;
+        while (taken < want && !leaves.d.empty()) {
+            KNode* o = leaves.pop();
+            if (o->queued || o->kid[0] || o->kid[1] || !worth_expanding(o)) continue;   // stale entry
+            o->queued = true;
+            jobs.push_back({o, 0}); jobs.push_back({o, 1});
+            ++taken;
+        }
+        return taken;
     }
 
     // relaxed vector of an evaluated node (host, O(n); only on incumbent updates)
@@ -250,20 +291,20 @@ struct Search {
             }
             return true;
         }
+        if ((!node->kid[0] || !node->kid[1]) && in_flight()) finish_jobs();      // it may be in the batch that is on the device
         if (!node->kid[0] || !node->kid[1]) {
             // one launch: this node's children plus those of the best evaluated leaves -- the nodes the search pops next
             std::vector<Job> jobs;
             for (int v = 0; v < 2; ++v) if (!node->kid[v]) jobs.push_back({node, v});
             node->queued = true;
-            int taken = 0;
-            while (taken < spec && !leaves.d.empty()) {
-                KNode* o = leaves.pop();
-                if (o->queued || o->kid[0] || o->kid[1] || !worth_expanding(o)) continue;   // stale entry
-                o->queued = true;
-                jobs.push_back({o, 0}); jobs.push_back({o, 1});
-                ++taken;
-            }
-            run_jobs(jobs);
+            take_leaves(jobs, spec);
+            run_jobs(jobs); ++n_sync;
+        }
+        // keep the device busy while the host replays: as soon as enough leaves have gathered, their expansion is enqueued and
+        // collected only when the search reaches one of them (or the next batch is due)
+        if (use_store && !in_flight() && (int)leaves.d.size() >= spec) {
+            std::vector<Job> jobs;
+            if (take_leaves(jobs, spec) > 0) { begin_jobs(jobs); ++n_async; }
         }
         relaxations += 2;
         consider_child(pq, node, 0);                                        // LEFT  x=0, :207-264
@@ -342,6 +383,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
             for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i].n);
             pq.d.swap(mine.d);
             replicated = false;
+            S.finish_jobs();
             S.reseed_leaves(pq);
             if (rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }   // rank 0 accounts for the warm-up
         }
@@ -369,6 +411,11 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
         if (own == -(double)rank && S.has_best && S.bestX[0] >= 0) for (int i = 0; i < n; ++i) xs[i] = S.bestX[i];
         if (own != -INFINITY) { opt.allreduce_max(xs.data(), n); for (int i = 0; i < n; ++i) S.bestX[i] = (int32_t)xs[i]; }
     }
+
+    S.finish_jobs();                                                        // a batch evaluated ahead may still be on the device
+    if (const char* dbg = std::getenv("LPX_KNAP_DEBUG")) if (dbg[0] == '1')
+        std::fprintf(stderr, "[lpx knap] sync launches %lld, async %lld, jobs %lld, begin %.1f ms, wait %.1f ms, device calls %.1f ms\n",
+                     (long long)S.n_sync, (long long)S.n_async, (long long)S.jobs_run, S.begin_ms, S.wait_ms, S.dev_ms);
 
     // final report, :368-405 ("Report = finalReport, Summary = \"\"")
     std::string fr = "Final Report:\nBranch & Bound Knapsack Finished.\n\n";

@@ -550,6 +550,7 @@ struct lpx_knapsack {
     std::vector<uint32_t*> node_list; std::vector<int32_t> node_depth;      // node id -> (list, depth)
     char* d_jobs = nullptr; char* h_jobs = nullptr; size_t jobs_cap = 0;
     bool wide = true;                                                        // LPX_KNAP_WIDE=0: always the one-probe-per-step kernel
+    int pending_out = 0;                                                     // results of the batch in flight (expand_begin .. expand_finish)
 };
 
 static constexpr size_t KN_CHUNK_WORDS = (size_t)16 << 20;                   // 64 MiB of uint32
@@ -706,11 +707,11 @@ int lpx_knapsack_relax_batch2(lpx_knapsack* k, int count, const int32_t* off, co
 
 int lpx_knapsack_has_prefix(lpx_knapsack* k) { return k && k->prefix_ok ? 1 : 0; }
 
-int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val,
-                              int64_t* child, double* profit, double* weight, int32_t* frac_idx, double* frac_val)
+int lpx_knapsack_expand_begin(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val, int64_t* child)
 {
-    if (!k || count < 0 || (count > 0 && (!parent || !item || !val || !child))) { set_error("lpx_knapsack_expand_batch: bad argument"); return LPX_EINVAL; }
+    if (!k || count < 0 || (count > 0 && (!parent || !item || !val || !child))) { set_error("lpx_knapsack_expand_begin: bad argument"); return LPX_EINVAL; }
     if (!k->prefix_ok) { set_error("lpx_knapsack_expand_batch needs the prefix-sum path (non-negative weights)"); return LPX_EINVAL; }
+    if (k->pending_out) { set_error("lpx_knapsack_expand_begin: a batch is already in flight (lpx_knapsack_expand_finish first)"); return LPX_EINVAL; }
     if (count == 0) return 0;
     const int64_t known = (int64_t)k->node_list.size();
     for (int j = 0; j < count; ++j) {
@@ -782,12 +783,35 @@ int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent,
     else
         hipLaunchKernelGGL(knap_expand, dim3((count + 3) / 4), dim3(256), 0, s, P, X, reinterpret_cast<const KnJob*>(k->h_jobs));
     LPX_HIP_TRY(hipGetLastError());
-    LPX_HIP_TRY(hipStreamSynchronize(s));
+    k->pending_out = nout;
+    return 0;
+}
+
+// Waits for the batch lpx_knapsack_expand_begin enqueued and hands out its 3 * count results (slot layout as
+// lpx_knapsack_expand_batch).  The host is free between the two calls: the jobs and the results live in pinned memory the
+// kernel reads and writes directly.
+int lpx_knapsack_expand_finish(lpx_knapsack* k, double* profit, double* weight, int32_t* frac_idx, double* frac_val)
+{
+    if (!k) { set_error("lpx_knapsack_expand_finish: null handle"); return LPX_EINVAL; }
+    const int nout = k->pending_out;
+    if (nout <= 0) return 0;
+    LPX_HIP_TRY(hipStreamSynchronize(k->stream));
+    k->pending_out = 0;
+    const size_t o_p = 0, o_w = sizeof(double) * nout, o_fv = 2 * sizeof(double) * nout, o_fr = 3 * sizeof(double) * nout;
     if (profit) std::memcpy(profit, k->h_out + o_p, sizeof(double) * nout);
     if (weight) std::memcpy(weight, k->h_out + o_w, sizeof(double) * nout);
     if (frac_val) std::memcpy(frac_val, k->h_out + o_fv, sizeof(double) * nout);
     if (frac_idx) std::memcpy(frac_idx, k->h_out + o_fr, sizeof(int32_t) * nout);
     return 0;
+}
+
+int lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val,
+                              int64_t* child, double* profit, double* weight, int32_t* frac_idx, double* frac_val)
+{
+    if (k && k->pending_out) { set_error("lpx_knapsack_expand_batch: a batch is in flight (lpx_knapsack_expand_finish first)"); return LPX_EINVAL; }
+    int rc = lpx_knapsack_expand_begin(k, count, parent, item, val, child);
+    if (rc) return rc;
+    return lpx_knapsack_expand_finish(k, profit, weight, frac_idx, frac_val);
 }
 
 int lpx_knapsack_node_list(lpx_knapsack* k, int64_t node, int32_t* idx, int8_t* val, int cap, int* depth)
