@@ -99,12 +99,26 @@ struct Search {
     double dev_ms = 0;                                   // wall time inside the lpx_knapsack_* calls (launch + wait)
     int spec = 256;                                      // evaluated leaves expanded ahead of the search per launch
     std::function<int(int, const int32_t*, const int32_t*, const int8_t*, double*, double*, int32_t*, double*)> test_relax;
-    std::deque<KNode> arena;                             // the evaluated tree (stable addresses)
+    // the evaluated tree: nodes are carved from raw 64k-node slabs and every field is written by the caller (root: eval_root,
+    // others: integrate) -- three nodes per job make a constructor call and a deque bookkeeping step per node measurable
+    std::vector<KNode*> slabs; size_t slab_used = 0;
+    static constexpr size_t SLAB = (size_t)1 << 16;
+    ~Search() { for (KNode* p : slabs) std::free(p); }
     Heap leaves;                                         // evaluated, unexpanded, still worth expanding: keyed by bound
     bool depth2 = false;                                 // one launch also evaluates each job's two children
     bool use_store = false;                              // device-resident node lists (lpx_knapsack_expand_batch)
 
-    KNode* alloc() { arena.emplace_back(); return &arena.back(); }
+    KNode* alloc()
+    {
+        if (slabs.empty() || slab_used == SLAB) {
+            KNode* p = static_cast<KNode*>(std::malloc(sizeof(KNode) * SLAB));
+            if (!p) throw LpxException(LPX_ENOMEM, "knapsack: out of host memory for the evaluated tree");
+            slabs.push_back(p); slab_used = 0;
+        }
+        KNode* x = slabs.back() + slab_used++;
+        x->kid[0] = nullptr; x->kid[1] = nullptr; x->queued = false;
+        return x;
+    }
     bool worth_expanding(const KNode* x) const           // would the search branch on it if it popped it now?
     { return x->self.frac >= 0 && x->self.weight <= cap + EPS && x->self.profit > best + EPS; }
     void offer_leaf(KNode* x) { if (!x->kid[0] && !x->kid[1] && worth_expanding(x)) leaves.push(x); }
@@ -369,6 +383,7 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
 
     Heap pq;
     KNode* root = S.alloc();                                                // :102-113
+    root->parent = nullptr; root->item = -1; root->val = 0; root->depth = 0; root->dev = -1;
     S.eval_root(root); S.relaxations++;
     pq.push(root);
     S.max_heap = 1;
