@@ -17,14 +17,15 @@ c, A, b = synth.dense_lp(m, n)
 T, basis = synth.primal_tableau_from(c, A, b)
 dt = L.DeviceTableau.from_host(T, basis)
 dt.snapshot()
-dt.primal_run()
+cap = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+dt.primal_run(max_iter=cap)
 dt.restore()
 out = (C.c_ulonglong * 16)()
 lib.lpx_debug_ws(dt._h, out, 16, 1)
 hs = (C.c_ulonglong * 32)()
 lib.lpx_debug_hs(hs, 1)
 
-status, st = dt.primal_run(use_graph=1, batch=64)
+status, st = dt.primal_run(use_graph=1, batch=64, max_iter=cap)
 lib.lpx_debug_ws(dt._h, out, 16, 0)
 lib.lpx_debug_hs(hs, 0)
 v = list(out)
