@@ -359,7 +359,7 @@ static constexpr int UPD_ROWS = 8;
 // policy wins (4096 x 8192 = 256 MiB: 77.7 us vs 83-88 us), so the launcher switches on the tableau's size.
 static constexpr int UPDS_NT = 64;
 static constexpr int UPDS_ROWS = 3;
-static constexpr size_t UPD_STREAM_BYTES = (size_t)320 << 20;
+static constexpr size_t UPD_STREAM_BYTES = (size_t)292 << 20;   // 306 MB: measured crossover (282 / 298 MB: this kernel wins, 315 MB: the mixed form)
 // UPDM: between the cache size and about twice it, storing ONE of the wave's three rows with the default policy (the other
 // two and all loads nontemporal) is worth another 6-8 %: a third of the tableau is then written through the Infinity
 // Cache and found there by the next pivot's loads.  Measured with the product's prologue (tools/kbench/sweep_dir.hip):

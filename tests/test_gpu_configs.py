@@ -190,7 +190,7 @@ def test_config5_root_bound_and_order(gpu, oracle):
 
 def test_dual_path_on_a_tableau_larger_than_the_infinity_cache(gpu, oracle):
     """lpx_update_s (the streaming variant of the dual / forced path's update kernel: 3 rows per wave, non-temporal loads and
-    stores) only runs above 320 MiB: a 4501 x 10001 dual tableau (361 MB), first pivots of ForceDualFeasibility + dual loop +
+    stores) only runs above 292 MiB: a 4501 x 10001 dual tableau (361 MB), first pivots of ForceDualFeasibility + dual loop +
     clean-up, bit-equal to the oracle."""
     m, n = 4500, 5500
     c, A, b = synth.dense_lp(m, n, seed=11)
@@ -200,7 +200,7 @@ def test_dual_path_on_a_tableau_larger_than_the_infinity_cache(gpu, oracle):
     for i in g.choice(m, size=12, replace=False):
         T[i, :n] *= -1.0
         T[i, -1] = -0.02 * T[i, -1]
-    assert T.nbytes > (320 << 20)
+    assert T.nbytes > (292 << 20)
     Tr, br = T.copy(), basis.copy()
     st_ref, tr_ref, nf = oracle.dual_tableau(Tr, br, fdf_guard=4, cleanup=1, max_iter=6)
     with gpu.DeviceTableau.from_host(T, basis) as dt:
