@@ -49,11 +49,12 @@ PROFILE_ROUND = "r02"
 def update_kernel(R, C):
     """(kernel name, grid size in threads) of the rank-1 update for an R x C tableau -- the key of the committed profile
     summaries.  Mirrors launch_update_mb (csrc/lpx_kernels.hip): tableaux above 292 MiB take a streaming variant (one wave
-    per workgroup, 3 rows per wave, non-temporal loads): up to 512 MiB with one row in three stored through the Infinity
-    Cache (`_m`), above with non-temporal stores throughout (`_s`); smaller ones the 8-row / 256-lane kernel."""
+    per workgroup, 3 rows per wave, non-temporal loads, one row in three of every ceil(bytes / 768 MiB)-th row block stored
+    through the Infinity Cache: `_m`; `_s`, non-temporal stores throughout, only beyond 8 GiB); smaller ones the 8-row /
+    256-lane kernel."""
     ld = (C + 15) // 16 * 16
     if 8 * ld * R > (292 << 20):
-        name = "lpx::lpx_update_mb_m" if 8 * ld * R <= (512 << 20) else "lpx::lpx_update_mb_s"
+        name = "lpx::lpx_update_mb_m" if 8 * ld * R <= (8192 << 20) else "lpx::lpx_update_mb_s"
         return name, ((ld + 127) // 128) * ((R + 2) // 3) * 64
     units = ((ld + 127) // 128) * ((R + 7) // 8)
     return "lpx::lpx_update_mb", ((units + 3) // 4) * 256

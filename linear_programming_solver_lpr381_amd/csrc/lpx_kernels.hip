@@ -7,6 +7,7 @@
 // Two launches per pivot on one stream:
 //   lpx_select  (1 workgroup x 1024 lanes)  ChooseEntering + ChooseLeaving + pivot prep
 //   lpx_update  (>> 256 workgroups)         rank-1 update of the whole tableau, HBM-bound
+#include <cstdlib>
 #include "lpx_resident.h"      // rs_hysteresis: the hysteresis scan over ratios held in LDS (also pulls in lpx_block.h)
 #include <hip/hip_ext.h>
 
@@ -360,12 +361,17 @@ static constexpr int UPD_ROWS = 8;
 static constexpr int UPDS_NT = 64;
 static constexpr int UPDS_ROWS = 3;
 static constexpr size_t UPD_STREAM_BYTES = (size_t)292 << 20;   // 306 MB: measured crossover (282 / 298 MB: this kernel wins, 315 MB: the mixed form)
-// UPDM: between the cache size and about twice it, storing ONE of the wave's three rows with the default policy (the other
-// two and all loads nontemporal) is worth another 6-8 %: a third of the tableau is then written through the Infinity
-// Cache and found there by the next pivot's loads.  Measured with the product's prologue (tools/kbench/sweep_dir.hip):
-// 4097 x 12289 (403 MB) 123.5 us all-nt -> 117.4 us, 5001 x 12001 (480 MB) the same ratio; at 576 MB the two forms meet,
-// from 784 MB on a third of the tableau no longer fits and the mixed form LOSES 12 % -- hence the upper bound.
-static constexpr size_t UPD_MIXED_BYTES = (size_t)512 << 20;
+// UPDM: above the cache size, storing ONE of the wave's three rows with the default policy (the other two and all loads
+// nontemporal) is worth 5-8 %: that row is written through the Infinity Cache and found there by the next pivot's loads --
+// as long as what is kept amounts to about one cache-full.  Measured on the product (tools/probe_policy.py, HIP events) and
+// with every store's policy read off the ISA (tools/kbench/sweep_dir.hip, profiles/r02_kbench_sweep_dir.txt):
+//   403 / 576 / 784 MB, all nt 126 / 185 / 249 us, LAST row default 116 / 167 / 228 us (first row: 119 / 172 / 229);
+//   two rows default: 116 us at 403 MB, 195-202 us at 576 MB (it no longer fits), all default 140 us;
+//   1074 / 1441 MB: one row in three no longer fits (347 / 499 us vs 342 / 462 all nt); the same row in every SECOND row
+//   block (a sixth of the tableau) 330 / 447 us.
+// Hence: one row in three of every `mixmod`-th row block, mixmod = ceil(bytes / 768 MiB); all-nt beyond 8 GiB (unmeasured).
+static constexpr size_t UPD_MIXED_BYTES = (size_t)8192 << 20;
+static constexpr size_t UPD_MIX_STEP_BYTES = (size_t)768 << 20;
 
 typedef double lpx_d2 __attribute__((ext_vector_type(2)));
 // __builtin_nontemporal_load / _store lower to global_load_dwordx4 / global_store_dwordx4 ... nt on gfx950 and stay inside
@@ -396,7 +402,7 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
                                                 double* fac0, double* fac1,
                                                 double* __restrict__ rhsbuf,
                                                 const DevState* __restrict__ st,
-                                                int ncw, int nunits)
+                                                int ncw, int nunits, int mixmod = 1)
 {
     if (st->status != LPX_RUNNING) return;
     const int r = st->r;
@@ -435,10 +441,16 @@ __device__ __forceinline__ void lpx_update_body(double* __restrict__ T, int ld, 
             v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
             v[k].y = v[k].y - f[k] * p.y;
         }
+        // mixed form: the LAST row of the wave goes through the Infinity Cache (default policy) in every `mixmod`-th row
+        // block, everything else is non-temporal; two spelled-out sequences so that no store loses its policy when the
+        // compiler merges code (checked in the ISA: hipcc keeps `nt` as metadata only)
+        if (POLICY == 2 && (mixmod <= 1 || rb % mixmod == 0)) {
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if (POLICY == 2 && k == 0) upd_store<false>(base + (size_t)k * ld, v[k]);
-            else upd_store<NT>(base + (size_t)k * ld, v[k]);
+            for (int k = 0; k < ROWS - 1; ++k) upd_store<true>(base + (size_t)k * ld, v[k]);
+            upd_store<false>(base + (size_t)(ROWS - 1) * ld, v[ROWS - 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) upd_store<NT>(base + (size_t)k * ld, v[k]);
         }
         return;
     }
@@ -646,7 +658,7 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
                                                    const DevState* __restrict__ st, DevState* us,
                                                    const double* __restrict__ part_v,
                                                    const int32_t* __restrict__ part_i, int nblk,
-                                                   int forced, int ncw, int nunits)
+                                                   int forced, int ncw, int nunits, int mixmod = 1)
 {
     constexpr bool NT = POLICY != 0;
     // The state record is read FIRST: a launch that finds the loop finished (tail of a batch, finished node
@@ -717,10 +729,16 @@ __device__ __forceinline__ void lpx_update_mb_body(double* __restrict__ T, int l
             v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
             v[k].y = v[k].y - f[k] * p.y;
         }
+        // mixed form: the LAST row of the wave goes through the Infinity Cache (default policy) in every `mixmod`-th row
+        // block, everything else is non-temporal; two spelled-out sequences so that no store loses its policy when the
+        // compiler merges code (checked in the ISA: hipcc keeps `nt` as metadata only)
+        if (POLICY == 2 && (mixmod <= 1 || rb % mixmod == 0)) {
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if (POLICY == 2 && k == 0) upd_store<false>(base + (size_t)k * ld, v[k]);
-            else upd_store<NT>(base + (size_t)k * ld, v[k]);
+            for (int k = 0; k < ROWS - 1; ++k) upd_store<true>(base + (size_t)k * ld, v[k]);
+            upd_store<false>(base + (size_t)(ROWS - 1) * ld, v[ROWS - 1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) upd_store<NT>(base + (size_t)k * ld, v[k]);
         }
         return;
     }
@@ -795,29 +813,29 @@ __global__ __launch_bounds__(UPD_NT) void lpx_update_mb(double* T, int ld, int R
 // streaming variants (tableau larger than the Infinity Cache): see UPDS_ROWS above
 __global__ __launch_bounds__(UPDS_NT) void lpx_update_s(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
                                                         const double* prow, double* fac0, double* fac1, double* rhsbuf,
-                                                        const DevState* st, int ncw, int nunits)
+                                                        const DevState* st, int ncw, int nunits, int mixmod)
 {
-    lpx_update_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+    lpx_update_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
 }
 __global__ __launch_bounds__(UPDS_NT) void lpx_update_m(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
                                                         const double* prow, double* fac0, double* fac1, double* rhsbuf,
-                                                        const DevState* st, int ncw, int nunits)
+                                                        const DevState* st, int ncw, int nunits, int mixmod)
 {
-    lpx_update_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+    lpx_update_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
 }
 __global__ __launch_bounds__(UPDS_NT) void lpx_update_mb_s(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
                                                            const double* prow, double* fac0, double* fac1, double* rhsbuf,
                                                            const DevState* st, DevState* us, const double* part_v,
-                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
+                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits, int mixmod)
 {
-    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 1>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits, mixmod);
 }
 __global__ __launch_bounds__(UPDS_NT) void lpx_update_mb_m(double* T, int ld, int Rcap, int Ccap, const int32_t* shape,
                                                            const double* prow, double* fac0, double* fac1, double* rhsbuf,
                                                            const DevState* st, DevState* us, const double* part_v,
-                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits)
+                                                           const int32_t* part_i, int nblk, int forced, int ncw, int nunits, int mixmod)
 {
-    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits);
+    lpx_update_mb_body<UPDS_ROWS, UPDS_NT, 2>(T, ld, Rcap, Ccap, shape, prow, fac0, fac1, rhsbuf, st, us, part_v, part_i, nblk, forced, ncw, nunits, mixmod);
 }
 // batched: every node of the group advances by one pivot per launch pair; grid.x covers the largest node
 __global__ __launch_bounds__(UPD_NT) void lpx_update_b(const SelParams* __restrict__ arr)
@@ -997,9 +1015,21 @@ hipError_t launch_select_mb(const SelParams& p, hipStream_t s)
 // which streaming form a tableau of `bytes` takes: 0 = none (it lives in the Infinity Cache), 2 = mixed store policy, 1 = all nt
 int update_policy(int ld, int R)
 {
+    // LPX_UPDATE_POLICY=0|1|2 forces one form (diagnostic: tools/probe_policy.py measures the three on one tableau)
+    static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_POLICY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    if (forced >= 0) return forced;
     const size_t bytes = sizeof(double) * (size_t)ld * (size_t)R;
     if (bytes <= UPD_STREAM_BYTES) return 0;
     return bytes <= UPD_MIXED_BYTES ? 2 : 1;
+}
+// every `mixmod`-th row block of the mixed form keeps one row in three in the cache: about a cache-full of the tableau in all
+// (256 MiB at 768 MiB -> every block up to there, every second block up to 1.5 GiB, ...)
+static int update_mixmod(int ld, int R)
+{
+    static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_MIXMOD"); return e ? std::atoi(e) : 0; }();   // diagnostic
+    if (forced > 0) return forced;
+    const size_t bytes = sizeof(double) * (size_t)ld * (size_t)R;
+    return (int)((bytes + UPD_MIX_STEP_BYTES - 1) / UPD_MIX_STEP_BYTES);
 }
 
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
@@ -1009,16 +1039,28 @@ hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0, hi
     const int rows = pol ? UPDS_ROWS : UPD_ROWS, nth = pol ? UPDS_NT : UPD_NT;
     const int ncw = (p.ld + 127) / 128, nunits = ncw * ((p.R + rows - 1) / rows);
     const int nblocks = (nunits + (nth / 64) - 1) / (nth / 64);
-    auto kern = pol == 0 ? lpx_update_mb : pol == 2 ? lpx_update_mb_m : lpx_update_mb_s;
     const int forced = p.mode == MODE_FORCED ? 1 : 0;
+    if (pol == 0) {
+        if (e0 && e1)
+            hipExtLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
+                                  (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                                  (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+        else
+            hipLaunchKernelGGL(lpx_update_mb, dim3(nblocks), dim3(nth), 0, s, p.T, p.ld, p.R, p.C, p.shape,
+                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
+                               (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+        return hipGetLastError();
+    }
+    auto kern = pol == 2 ? lpx_update_mb_m : lpx_update_mb_s;
+    const int mixmod = update_mixmod(p.ld, p.R);
     if (e0 && e1)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, p.T, p.ld, p.R, p.C, p.shape,
                               (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
-                              (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+                              (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits, mixmod);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, p.T, p.ld, p.R, p.C, p.shape,
                            (const double*)p.prow, p.col0, p.col1, p.rhsbuf, (const DevState*)p.st, p.us,
-                           (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits);
+                           (const double*)p.part_v, (const int32_t*)p.part_i, p.nblk, forced, ncw, nunits, mixmod);
     return hipGetLastError();
 }
 
@@ -1069,11 +1111,19 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
     const int rows = pol ? UPDS_ROWS : UPD_ROWS, nth = pol ? UPDS_NT : UPD_NT;
     const int ncw = (ld + 127) / 128, nunits = ncw * ((R + rows - 1) / rows);
     const int nblocks = (nunits + (nth / 64) - 1) / (nth / 64);
-    auto kern = pol == 0 ? lpx_update : pol == 2 ? lpx_update_m : lpx_update_s;
+    if (pol == 0) {
+        if (e0 && e1)
+            hipExtLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        else
+            hipLaunchKernelGGL(lpx_update, dim3(nblocks), dim3(nth), 0, s, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        return hipGetLastError();
+    }
+    auto kern = pol == 2 ? lpx_update_m : lpx_update_s;
+    const int mixmod = update_mixmod(ld, R);
     if (e0 && e1)
-        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
     else
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
     return hipGetLastError();
 }
 

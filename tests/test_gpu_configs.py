@@ -30,12 +30,11 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-@pytest.mark.parametrize("R,C,count", [(4096, 8192, 12), (4097, 12289, 8), (4097, 17001, 6)])
+@pytest.mark.parametrize("R,C,count", [(4096, 8192, 12), (4097, 12289, 8)])
 def test_forced_pivots_bitwise_at_headline_shapes(gpu, oracle, R, C, count):
-    """K4 on the shapes the roofline is quoted on and on one of every update form (256 MiB: lpx_update_mb, cache policy
-    default; 403 MB: lpx_update_mb_m, one row in three stored through the Infinity Cache; 557 MB: lpx_update_mb_s, all
-    non-temporal -- the last two with the entering column reduced by select's last workgroup): every element of the tableau
-    after `count` pivots equals the oracle's (uint64 view), and so does every chosen pivot column."""
+    """K4 on the shapes the roofline is quoted on (256 MiB: lpx_update_mb, cache policy default; 403 MB: lpx_update_mb_m,
+    one row in three stored through the Infinity Cache, the entering column reduced by select's last workgroup): every
+    element of the tableau after `count` pivots equals the oracle's (uint64 view), and so does every chosen pivot column."""
     T0 = synth.raw_tableau(R, C)
     rows, cols = synth.forced_pivot_list(R, C, count)
     Tr = T0.copy()
@@ -45,6 +44,33 @@ def test_forced_pivots_bitwise_at_headline_shapes(gpu, oracle, R, C, count):
         Tg, _ = dt.download()
     assert chosen.tolist() == chosen_ref.tolist() and st["pivots"] == count
     assert np.array_equal(_bits(Tg), _bits(Tr))
+
+
+@pytest.mark.parametrize("env", [{"LPX_UPDATE_POLICY": "1"}, {"LPX_UPDATE_MIXMOD": "2"}, {"LPX_UPDATE_MIXMOD": "5"}])
+def test_every_streaming_update_form_is_bitwise(oracle, env):
+    """The forms the launcher picks for still larger tableaux -- all non-temporal (lpx_update_mb_s) and the thinner store mixes
+    (every 2nd / 5th row block keeps a row in the cache) -- forced onto the 403 MB tableau through the diagnostic knobs
+    (read once per process, hence the child process): same bits as the oracle after 6 forced pivots."""
+    R, C, count = 4097, 12289, 6
+    T0 = synth.raw_tableau(R, C)
+    rows, cols = synth.forced_pivot_list(R, C, count)
+    Tr = T0.copy()
+    chosen_ref = oracle.forced_pivots(Tr, rows, cols, 0.1)
+    want = hashlib.sha256(np.ascontiguousarray(Tr).view(np.uint8)).hexdigest()
+    code = textwrap.dedent(f"""
+        import hashlib, numpy as np
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        T0 = synth.raw_tableau({R}, {C}); rows, cols = synth.forced_pivot_list({R}, {C}, {count})
+        with L.DeviceTableau.from_host(T0) as dt:
+            chosen, st = dt.forced_pivots(rows, cols, 0.1)
+            Tg, _ = dt.download()
+        print(hashlib.sha256(np.ascontiguousarray(Tg).view(np.uint8)).hexdigest(), chosen.tolist() == {chosen_ref.tolist()!r}, st["pivots"])
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.strip().splitlines()[-1].split()
+    assert got == [want, "True", str(count)], (env, got)
 
 
 def test_primal_solve_first_pivots_of_the_4096x8192_lp(gpu, oracle):

@@ -5,9 +5,6 @@
 //   head  [0, a)      lines expected in the cache (written last by the previous sweep): loads default, stores nt
 //   body  [a, 1 - a)  streams through: loads nt, stores nt
 //   tail  [1 - a, 1)  to be kept for the next sweep: loads nt, stores default
-// (*) CAUTION about the `upd` switch kernel: the compiler merges the tails of its mode blocks, so the store policy of a row
-// is not always what the source says for that mode (its third store comes out with the default policy).  That is how the
-// store mix was found; upd_exp / upd_mask / upd_cand are the controlled forms and the ones the product kernel follows.
 // hipcc --offload-arch=gfx950 -O3 -ffp-contract=off sweep_dir.hip -o sweep_dir ; ./sweep_dir [R C reps]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -22,8 +19,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 template <bool NT> __device__ __forceinline__ d2 ld2(const double* p)
 { if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p)); return *reinterpret_cast<const d2*>(p); }
+// The nontemporal STORE is written as inline assembly here: hipcc keeps `nt` as metadata on the store and drops it when it
+// merges or reorders the stores of an unrolled loop -- the first version of this file measured variants whose code was not
+// what their source said (two of three "nt" stores came out with the default policy).  With the instruction spelled out the
+// policy of every variant is what its label says (checked in the ISA: llvm-objdump -d, or hipcc -S).  s_nop: the store reads
+// its data registers after issue (cdna_hip_programming.md 5.7).
 template <bool NT> __device__ __forceinline__ void st2(double* p, d2 v)
-{ if (NT) __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p)); else *reinterpret_cast<d2*>(p) = v; }
+{
+    if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<d2*>(p) = v;
+}
 
 // one wave per block: ROWS rows x 128 columns; mode: 0 = uniform (LNT/SNT), 1 = positional
 template <int ROWS, bool LNT, bool SNT>
@@ -408,6 +413,40 @@ __global__ __launch_bounds__(64) void upd_cand(double* __restrict__ T, int ld, i
     }
 }
 
+// thinner store mix for tableaux beyond twice the cache: only every MOD-th row block stores its first row with the default
+// policy (1 / (3 MOD) of the tableau goes through the Infinity Cache)
+template <int ROWS, int MOD>
+__global__ __launch_bounds__(64) void upd_thin(double* __restrict__ T, int ld, int R, const double* __restrict__ prow, const double* __restrict__ fac,
+                                               int r, int ncw, int nrb)
+{
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int cw = unit % ncw, rb = unit / ncw;
+    const int col = cw * 128 + lane * 2;
+    if (col >= ld) return;
+    const int row0 = rb * ROWS;
+    double* base = T + (size_t)row0 * ld + col;
+    const d2 p = *reinterpret_cast<const d2*>(prow + col);
+    if (row0 + ROWS <= R && (r < row0 || r >= row0 + ROWS)) {
+        d2 v[ROWS]; double f[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) v[k] = ld2<true>(base + (size_t)k * ld);
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) f[k] = fac[row0 + k];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) { v[k].x = v[k].x - f[k] * p.x; v[k].y = v[k].y - f[k] * p.y; }
+        if (rb % MOD == 0) st2<false>(base, v[0]); else st2<true>(base, v[0]);
+#pragma unroll
+        for (int k = 1; k < ROWS; ++k) st2<true>(base + (size_t)k * ld, v[k]);
+        return;
+    }
+#pragma unroll 1
+    for (int k = 0; k < ROWS; ++k) {
+        const int i = row0 + k;
+        if (i < R && i != r) { const d2 v = ld2<true>(base + (size_t)k * ld); const double f = fac[i]; d2 o; o.x = v.x - f * p.x; o.y = v.y - f * p.y; st2<true>(base + (size_t)k * ld, o); }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int R = argc > 1 ? atoi(argv[1]) : 4097, C = argc > 2 ? atoi(argv[2]) : 12289, reps = argc > 3 ? atoi(argv[3]) : 60;
@@ -426,7 +465,7 @@ int main(int argc, char** argv)
     printf("R=%d C=%d ld=%d  tableau %.1f MB, algorithmic bytes per launch %.1f MB, %d units\n", R, C, ld, tab_mb, bytes / 1e6, total);
     struct V { std::string name; int mode; bool alt; double head_mb, tail_mb; };
     std::vector<V> vs = {
-        {"switch kernel, mode nt/nt, one direction (*)", 0, false, 0, 0},
+        {"nt/nt one direction", 0, false, 0, 0},
         {"nt/nt alternating", 0, true, 0, 0},
         {"default/default one direction", 1, false, 0, 0},
         {"default/default alternating", 1, true, 0, 0},
@@ -500,6 +539,11 @@ int main(int argc, char** argv)
         cv.push_back({"cand: NO reduction, default,nt,nt, tiles hoisted", [=] { hipLaunchKernelGGL((upd_cand<ROWS, 6, true, true, false>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, fac1, dst, pv, pi, nxt, ncw, nrb); }});
         cv.push_back({"cand: reduction, partial + tile loads hoisted, default,nt,nt", [=] { hipLaunchKernelGGL((upd_cand<ROWS, 6, true, false, true>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, fac1, dst, pv, pi, nxt, ncw, nrb); }});
         cv.push_back({"cand: NO reduction, stores nt x3", [=] { hipLaunchKernelGGL((upd_cand<ROWS, 7, false, true, false>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, fac1, dst, pv, pi, nxt, ncw, nrb); }});
+        cv.push_back({"thin mix: first row default in every 1-th row block (1/3 of the tableau)", [=] { hipLaunchKernelGGL((upd_thin<ROWS, 1>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb); }});
+        cv.push_back({"thin mix: first row default in every 2-th row block (1/6 of the tableau)", [=] { hipLaunchKernelGGL((upd_thin<ROWS, 2>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb); }});
+        cv.push_back({"thin mix: first row default in every 3-th row block (1/9 of the tableau)", [=] { hipLaunchKernelGGL((upd_thin<ROWS, 3>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb); }});
+        cv.push_back({"thin mix: first row default in every 4-th row block (1/12 of the tableau)", [=] { hipLaunchKernelGGL((upd_thin<ROWS, 4>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb); }});
+        cv.push_back({"thin mix: first row default in every 6-th row block (1/18 of the tableau)", [=] { hipLaunchKernelGGL((upd_thin<ROWS, 6>), dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb); }});
         cv.push_back({"plain upd kernel (mode 0) again", [=] { hipLaunchKernelGGL(upd<ROWS>, dim3(total), dim3(64), 0, s, T, ld, R, prow, fac, 7, ncw, nrb, 0, 0, 0, 0); }});
         for (int pass = 0; pass < 2; ++pass)
             for (auto& c : cv) {
