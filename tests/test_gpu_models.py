@@ -492,3 +492,35 @@ def test_batched_solution_readback_and_parking_equal_the_per_node_calls(gpu):
         lib.lpx_store_destroy(store)
         for t in ts:
             t.close()
+
+
+def test_knapsack_expand_in_two_halves_equals_the_batch_call(gpu):
+    """lpx_knapsack_expand_begin / _finish (the host works while the device evaluates) give what lpx_knapsack_expand_batch
+    gives; a second _begin while a batch is in flight is refused, _finish without a batch is a no-op."""
+    import ctypes as C
+    lib = gpu._lib.lib()
+    g = np.random.default_rng(12)
+    n = 4000
+    w = g.integers(1, 1001, size=n).astype(float); p = w + g.integers(0, 101, size=n)
+    cap = float(np.floor(0.5 * w.sum()))
+    a, b = gpu.DeviceKnapsack(p, w, cap), gpu.DeviceKnapsack(p, w, cap)
+    try:
+        parents = [-1] * 5; items = [int(i) for i in g.choice(n, 5, replace=False)]; vals = [0, 1, 0, 1, 1]
+        ids_b, P, W, F, X = b.expand_batch(parents, items, vals)
+        par = np.asarray(parents, np.int64); it = np.asarray(items, np.int32); vv = np.asarray(vals, np.int8)
+        ids = np.zeros(5, np.int64)
+        args = (a._h, 5, par.ctypes.data_as(C.POINTER(C.c_int64)), it.ctypes.data_as(gpu._lib.ip), vv.ctypes.data_as(C.POINTER(C.c_int8)),
+                ids.ctypes.data_as(C.POINTER(C.c_int64)))
+        assert lib.lpx_knapsack_expand_finish(a._h, None, None, None, None) == 0          # nothing in flight
+        gpu._lib.check(lib.lpx_knapsack_expand_begin(*args))
+        assert lib.lpx_knapsack_expand_begin(*args) < 0                                   # one batch per handle
+        pp = np.zeros(15); ww = np.zeros(15); fr = np.zeros(15, np.int32); fx = np.zeros(15)
+        gpu._lib.check(lib.lpx_knapsack_expand_finish(a._h, pp.ctypes.data_as(gpu._lib.dp), ww.ctypes.data_as(gpu._lib.dp),
+                                                      fr.ctypes.data_as(gpu._lib.ip), fx.ctypes.data_as(gpu._lib.dp)))
+        live = F.reshape(-1) != -2
+        assert ids.tolist() == ids_b.tolist() and fr.tolist() == F.reshape(-1).tolist()
+        assert np.array_equal(pp[live], P.reshape(-1)[live]) and np.array_equal(ww[live], W.reshape(-1)[live]) and np.array_equal(fx[live], X.reshape(-1)[live])
+        for j in range(5):
+            assert a.node_list(int(ids[j])) == b.node_list(int(ids_b[j])) == {items[j]: vals[j]}
+    finally:
+        a.close(); b.close()
