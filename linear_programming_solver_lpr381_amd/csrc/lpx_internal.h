@@ -150,13 +150,22 @@ int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, lon
 // runs on different streams overlap on the device (lpx_multi_run).
 class LoopRun {
 public:
+    LoopRun() = default;
+    LoopRun(const LoopRun&) = delete;
+    LoopRun& operator=(const LoopRun&) = delete;
     int begin(const LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
               lpx_pivot_cb cb, void* user);
     int submit();
     int complete();
     bool done() const { return status_ != LPX_RUNNING || enq_ >= budget_; }
+    bool may_submit() const { return enq_ < budget_; }
+    int in_flight() const { return head_ - tail_; }
     int finish(lpx_stats* stats);          // returns the final status (or an error)
+    ~LoopRun();
 private:
+    // up to two batches in flight: each submit() copies the state into its own pinned slot and records its own event, so
+    // complete() waits for the OLDEST batch only while the next one is already queued behind it (run_device_loop)
+    DevState* stage_ = nullptr; hipEvent_t ev_[2] = {nullptr, nullptr}; int head_ = 0, tail_ = 0;
     LoopCtx c_; lpx_run_opts o_{}; long long budget_ = 0, enq_ = 0;
     lpx_pivot_cb cb_ = nullptr; void* user_ = nullptr;
     lpx_stats local_{}; int batch_ = 64; bool graph_ = false;
