@@ -1,0 +1,56 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a world_size-2 job whose ranks SHARE the visible GPU.  The searches,
+the device loops and the node store are the product's; the per-level exchange is all_reduce(MAX) over gloo on CPU tensors
+(the rehearsal backend of bench.py -- on a multi-GPU node the same callback runs over RCCL)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+import linear_programming_solver_lpr381_amd as L
+from linear_programming_solver_lpr381_amd import synth
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L._lib.check(L._lib.lib().lpx_init(0))
+    calls = {"n": 0}
+
+    def allreduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        calls["n"] += 1
+        return t.numpy()
+
+    res = {"rank": rank}
+    # a 0/1 IP small enough to be solved: cold level search with the depth-first-K pool, then the warm-started one
+    cs, As, rels, bs = synth.binary_ip(24, 8, seed=11)
+    ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)
+    for name, kw in (("cold", dict(bnb_search=1, bnb_dive=1, concurrent_nodes=8)), ("warm", dict(bnb_search=2, concurrent_nodes=8))):
+        calls["n"] = 0
+        r = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw).Solve(ps)
+        res[name] = {"z": r.OptimalValue, "x": np.asarray(r.Solution).tolist() if r.Solution is not None else None,
+                     "lp_solves": r.LpSolves, "nodes": r.Nodes, "allreduces": calls["n"], "aux": list(r.Aux)}
+    # knapsack solved to exhaustion through the device node store (evaluated tree re-seeded after the split)
+    g = np.random.default_rng(3)
+    n = 300
+    w = g.integers(1, 60, size=n).astype(float); p = w + g.integers(0, 12, size=n)
+    cap = float(np.floor(0.5 * w.sum()))
+    kp = L.LPProblem(L.Sense.Max, p.tolist(), [L.Constraint(w.tolist(), L.Rel.LE, cap)])
+    calls["n"] = 0
+    rk = L.BranchAndBoundKnapsack(max_nodes=0, concurrent_nodes=64, rank=rank, world=world, allreduce_max=allreduce_max).Solve(kp)
+    res["knap"] = {"z": rk.OptimalValue, "x": rk.Extra.astype(int).tolist(), "popped": rk.Nodes, "allreduces": calls["n"]}
+    json.dump(res, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
