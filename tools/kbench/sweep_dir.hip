@@ -23,7 +23,11 @@ template <bool NT> __device__ __forceinline__ d2 ld2(const double* p)
 // merges or reorders the stores of an unrolled loop -- the first version of this file measured variants whose code was not
 // what their source said (two of three "nt" stores came out with the default policy).  With the instruction spelled out the
 // policy of every variant is what its label says (checked in the ISA: llvm-objdump -d, or hipcc -S).  s_nop: the store reads
-// its data registers after issue (cdna_hip_programming.md 5.7).
+// its data registers after issue (cdna_hip_programming.md 5.7).  LOADS keep the builtin (an inline-asm load is invisible to
+// hipcc's wait counts): the same merging can strip `nt` from loads when ONE kernel mixes load policies, so only variants
+// with a uniform load policy are quoted anywhere (exp / thin / cand / the uniform nt and default kernels; their loads were
+// checked: three `global_load_dwordx4 ... nt`).  The two `upd` modes and the positional variants that mix LOAD policies
+// are exploratory only.
 template <bool NT> __device__ __forceinline__ void st2(double* p, d2 v)
 {
     if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
