@@ -953,7 +953,7 @@ int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts
 
 // ---- parent store: final tableaux of solved nodes parked in slab slots (warm-started B&B children) ----------
 struct lpx_store {
-    int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 32;
+    int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 128;
     size_t slot_doubles = 0;                 // Rcap * ld
     std::vector<double*> chunks_T; std::vector<int32_t*> chunks_b;
     std::vector<int> R, C;                   // live shape per slot
