@@ -266,7 +266,8 @@ int  lpx_knapsack_has_prefix(lpx_knapsack* k);
  * job instead of the whole list.  Needs non-negative weights (lpx_knapsack_has_prefix). */
 int  lpx_knapsack_expand_batch(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val,
                                int64_t* child, double* profit, double* weight, int32_t* frac_idx, double* frac_val);
-/* The same in two halves, so that the host can work while the device does: _begin enqueues the batch (ids in child[] are valid
+/* The same in two halves (the children of Models/BranchAndBoundKnapsack.cs:207-209,:267-269 evaluated AHEAD of the loop that
+ * asks for them), so that the host can work while the device does: _begin enqueues the batch (ids in child[] are valid
  * at once), _finish waits for it and hands out the 3 * count results.  One batch in flight per handle. */
 int  lpx_knapsack_expand_begin(lpx_knapsack* k, int count, const int64_t* parent, const int32_t* item, const int8_t* val, int64_t* child);
 int  lpx_knapsack_expand_finish(lpx_knapsack* k, double* profit, double* weight, int32_t* frac_idx, double* frac_val);
