@@ -292,8 +292,8 @@ def main():
         cs, As, rels, bs = synth.binary_ip(args.bnb_prune_n, args.bnb_prune_m)
         ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)
         out["bnb_prune"] = bnb_leg(ps, f"random 0/1 IP n={args.bnb_prune_n} m={args.bnb_prune_m} (+{args.bnb_prune_n} bound rows), repaired mode, "
-                                       "sharded level search with the depth-first-K pool, solved to optimality (no node budget)",
-                                   bnb_search=1, bnb_dive=1, concurrent_nodes=32, max_nodes=0)
+                                       "sharded level search with the depth-first-K pool (128 node LPs per round, each resident in the LDS of one or two CUs), solved to optimality (no node budget)",
+                                   bnb_search=1, bnb_dive=1, concurrent_nodes=128, max_nodes=0)
         progress("knapsack leg (config 5)")
         # ---- config 5: sharded knapsack (all ranks) ---------------------------------------------------
         pk, wk, capk = synth.knapsack(100_000)

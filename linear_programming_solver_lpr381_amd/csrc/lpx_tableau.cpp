@@ -497,7 +497,11 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
     static int cus = 0;
     if (!cus) { if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0; cus = prop.multiProcessorCount; }
     const size_t lds_max = 160 * 1024 - 1024;
-    for (int n = count < 8 ? count : 8; n >= 1; --n) {
+    // As many nodes per launch as fit: a node takes cus / n workgroups, down to ONE (small node LPs: 240 of them side by side,
+    // each in the LDS of one CU).  r01 / early r02 stopped at 8 nodes per launch; a 60-variable 0/1 program went from 7.2 k to
+    // 21 k nodes/s when the limit fell (tools/probe_slots.py), node logs and pivot counts unchanged.  LPX_GROUP_SLOTS caps it.
+    static const int max_slots = [] { const char* e = std::getenv("LPX_GROUP_SLOTS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
+    for (int n = count < max_slots ? count : max_slots; n >= 1; --n) {
         int g = cus / n;
         size_t need = 0;
         for (int i = 0; i < count; ++i) {
