@@ -141,6 +141,11 @@ int lpx_tableau_solution(lpx_tableau* t, int nvars, double* x, double* z);
 int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts, const int32_t* var,
                            const double* coef, const double* zero, const double* rhs);
 
+/* The same for a group of nodes in one launch: node i gets the branching rows [cut_off[i], cut_off[i+1]) of the flattened
+ * arrays (cut_off has count + 1 entries, cut_off[0] = 0).  Returns when the nodes are built. */
+int lpx_tableau_build_nodes(lpx_tableau** nodes, const lpx_tableau* root, int count, const int32_t* cut_off,
+                            const int32_t* var, const double* coef, const double* zero, const double* rhs);
+
 /* Warm start of a branch-and-bound child (NOT what the reference does -- it re-solves every
  * node from the slack basis, Models/Branch&Bound.cs:148): `child` becomes `parent`'s final tableau plus the row
  * of `x_var <= bound` (is_ge = 0) or `x_var >= bound` (is_ge = 1) written in the parent's basis, where

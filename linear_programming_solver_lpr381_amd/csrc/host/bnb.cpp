@@ -419,11 +419,32 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     for (size_t a = 0; a < group.size(); a += width) {
         const size_t b = std::min(group.size(), a + width);
         std::vector<lpx_tableau*> hs; std::vector<int> dual; std::vector<NodeLP*> live;
-        for (size_t i = a; i < b; ++i) {
-            NodeLP* lp = group[i];
-            if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
-            { const double t0 = PhaseTimer::now(); upload(c, *lp); g_pt.build += PhaseTimer::now() - t0; }
-            hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
+        {
+            const double t0 = PhaseTimer::now();
+            std::vector<NodeLP*> assemble[2];                     // cold nodes built on the device, per root template: ONE launch each
+            for (size_t i = a; i < b; ++i) {
+                NodeLP* lp = group[i];
+                if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
+                if (lp->on_device && !lp->warm) {
+                    const int d = (int)lp->cvar.size(), w = lp->dual ? 1 : 0;
+                    lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));   // capacity classes of 32 levels (see upload)
+                    assemble[w].push_back(lp);
+                } else upload(c, *lp);
+                hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
+            }
+            for (int w = 0; w < 2; ++w) {
+                if (assemble[w].empty()) continue;
+                std::vector<lpx_tableau*> nh; std::vector<int32_t> off{0}, var; std::vector<double> coef, zero, rhs;
+                for (NodeLP* lp : assemble[w]) {
+                    nh.push_back(lp->h);
+                    var.insert(var.end(), lp->cvar.begin(), lp->cvar.end()); coef.insert(coef.end(), lp->ccoef.begin(), lp->ccoef.end());
+                    zero.insert(zero.end(), lp->czero.begin(), lp->czero.end()); rhs.insert(rhs.end(), lp->crhs.begin(), lp->crhs.end());
+                    off.push_back((int32_t)var.size());
+                }
+                int rc = lpx_tableau_build_nodes(nh.data(), c.root_tpl[w], (int)nh.size(), off.data(), var.data(), coef.data(), zero.data(), rhs.data());
+                if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            }
+            g_pt.build += PhaseTimer::now() - t0;
         }
         if (c.count_work) c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
         if (hs.empty()) continue;

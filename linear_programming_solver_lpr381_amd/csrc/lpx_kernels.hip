@@ -886,6 +886,50 @@ __global__ __launch_bounds__(256) void lpx_build_node(const double* __restrict__
     T[(size_t)i * ld + j] = v;
 }
 
+// The same for a whole group of nodes in ONE launch (blockIdx.z = node): small node LPs are solved hundreds at a time, and
+// a launch + two small copies per node were the largest host phase left.  The kernel also writes each node's live-shape
+// record and clears its state record.
+__global__ __launch_bounds__(256) void lpx_build_nodes(const double* __restrict__ T0, int ld0, int R0, int C0,
+                                                       const BuildDesc* __restrict__ descs,
+                                                       const int32_t* __restrict__ cvar, const double* __restrict__ ccoef,
+                                                       const double* __restrict__ czero, const double* __restrict__ crhs)
+{
+    const BuildDesc D = descs[blockIdx.z];
+    const int R = D.R, C = D.C, ld = D.ld;
+    const int m0 = R0 - 1, m = R - 1, n = C0 - R0;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= R) return;
+    if (i == 0 && blockIdx.x == 0) {
+        if (threadIdx.x == 0) { D.shape[0] = R; D.shape[1] = C; }
+        int32_t* stw = reinterpret_cast<int32_t*>(D.st);
+        for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 256) stw[k] = 0;
+    }
+    if (j == 0 && i < m) D.basis[i] = n + i;                             // :197
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < C) {
+        if (i < m0 || i == m) {                                          // root constraint rows / objective row
+            const int i0 = (i == m) ? m0 : i;
+            if (j < n + m0) v = T0[(size_t)i0 * ld0 + j];
+            else if (j == C - 1) v = T0[(size_t)i0 * ld0 + (C0 - 1)];
+        } else {                                                         // branching row k
+            const int k = D.cut0 + (i - m0);
+            if (j < n) v = (j == cvar[k]) ? ccoef[k] : czero[k];
+            else if (j == n + m0 + (i - m0)) v = 1.0;                    // its slack, :191
+            else if (j == C - 1) v = crhs[k];                            // :192
+        }
+    }
+    D.T[(size_t)i * ld + j] = v;
+}
+
+hipError_t launch_build_nodes(const double* T0, int ld0, int R0, int C0, const BuildDesc* descs, int count, int maxld, int maxR,
+                              const int32_t* cvar, const double* ccoef, const double* czero, const double* crhs, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_build_nodes, dim3((maxld + 255) / 256, maxR, count), dim3(256), 0, s, T0, ld0, R0, C0, descs, cvar, ccoef, czero, crhs);
+    return hipGetLastError();
+}
+
 // Warm start: the child of a solved node is the parent's FINAL tableau plus one branching
 // row expressed in the parent's basis.  With x_k basic in row ik:  `x_k <= f`  becomes  e_k - T[ik,:]  (rhs
 // f - x_k* < 0) and  `x_k >= c`  becomes  -e_k + T[ik,:]  (rhs -c + x_k* < 0); the new slack is basic in the new

@@ -955,6 +955,66 @@ int lpx_tableau_build_node(lpx_tableau* node, const lpx_tableau* root, int ncuts
     return 0;   // stream-ordered: the run that follows on node->stream sees the finished tableau
 }
 
+// lpx_tableau_build_node for a group of nodes in one launch: node i gets the cuts [cut_off[i], cut_off[i + 1]) of the
+// flattened arrays.  One H2D copy of the packed descriptors and cuts, one kernel, one wait.
+int lpx_tableau_build_nodes(lpx_tableau** nodes, const lpx_tableau* root, int count, const int32_t* cut_off,
+                            const int32_t* var, const double* coef, const double* zero, const double* rhs)
+{
+    if (!nodes || !root || count < 0 || !cut_off) { set_error("lpx_tableau_build_nodes: bad argument"); return LPX_EINVAL; }
+    if (count == 0) return 0;
+    const int total = cut_off[count];
+    if (cut_off[0] != 0 || total < 0 || (total > 0 && (!var || !coef || !zero || !rhs))) { set_error("lpx_tableau_build_nodes: bad cut arrays"); return LPX_EINVAL; }
+    const int n = root->C - root->R;
+    int maxld = 16, maxR = 1;
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* t = nodes[i];
+        const int nc = cut_off[i + 1] - cut_off[i];
+        if (!t || nc < 0) { set_error("lpx_tableau_build_nodes: null node or negative cut count"); return LPX_EINVAL; }
+        if (root->R + nc > t->Rcap || root->C + nc > t->Ccap) { set_error("lpx_tableau_build_nodes: root shape + ncuts exceeds a node handle's capacity"); return LPX_EINVAL; }
+        maxld = std::max(maxld, t->ld); maxR = std::max(maxR, root->R + nc);
+    }
+    for (int k = 0; k < total; ++k) if (var[k] < 0 || var[k] >= n) { set_error("lpx_tableau_build_nodes: branching variable out of range"); return LPX_EINVAL; }
+    struct Scratch { char* h = nullptr; char* d = nullptr; size_t cap = 0; };
+    static thread_local Scratch sc;             // never freed: the HIP runtime may be gone when thread-locals are torn down
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t tn = (size_t)(total > 0 ? total : 1);
+    const size_t o_desc = 0, o_coef = up16(sizeof(BuildDesc) * (size_t)count), o_zero = o_coef + up16(8 * tn), o_rhs = o_zero + up16(8 * tn),
+                 o_var = o_rhs + up16(8 * tn), need = o_var + up16(4 * tn);
+    if (need > sc.cap) {
+        if (sc.h) hipHostFree(sc.h);
+        hipFree(sc.d);
+        sc.h = nullptr; sc.d = nullptr; sc.cap = 0;
+        LPX_HIP_TRY(hipHostMalloc((void**)&sc.h, 2 * need));
+        LPX_HIP_TRY(hipMalloc((void**)&sc.d, 2 * need));
+        sc.cap = 2 * need;
+    }
+    hipStream_t s = nodes[0]->stream;
+    // every node's own stream has to be idle before another stream writes its tableau (and before the scratch is reused)
+    for (int i = 0; i < count; ++i) {
+        bool seen = false; for (int j = 0; j < i; ++j) if (nodes[j]->stream == nodes[i]->stream) { seen = true; break; }
+        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(nodes[i]->stream));
+    }
+    BuildDesc* d = reinterpret_cast<BuildDesc*>(sc.h + o_desc);
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* t = nodes[i];
+        const int nc = cut_off[i + 1] - cut_off[i];
+        t->R = root->R + nc; t->C = root->C + nc;
+        t->shape_h[0] = t->R; t->shape_h[1] = t->C;
+        d[i].T = t->T; d[i].basis = t->basis; d[i].shape = t->shape; d[i].st = t->st; d[i].ld = t->ld; d[i].R = t->R; d[i].C = t->C; d[i].cut0 = cut_off[i];
+    }
+    if (total > 0) {
+        std::memcpy(sc.h + o_coef, coef, 8 * (size_t)total); std::memcpy(sc.h + o_zero, zero, 8 * (size_t)total);
+        std::memcpy(sc.h + o_rhs, rhs, 8 * (size_t)total); std::memcpy(sc.h + o_var, var, 4 * (size_t)total);
+    }
+    LPX_HIP_TRY(hipMemcpyAsync(sc.d, sc.h, need, hipMemcpyHostToDevice, s));
+    const double* T0 = root->snapT ? root->snapT : root->T;          // the pristine root tableau
+    LPX_HIP_TRY(launch_build_nodes(T0, root->ld, root->R, root->C, reinterpret_cast<const BuildDesc*>(sc.d + o_desc), count, maxld, maxR,
+                                   reinterpret_cast<const int32_t*>(sc.d + o_var), reinterpret_cast<const double*>(sc.d + o_coef),
+                                   reinterpret_cast<const double*>(sc.d + o_zero), reinterpret_cast<const double*>(sc.d + o_rhs), s));
+    LPX_HIP_TRY(hipStreamSynchronize(s));       // the runs that follow use other streams
+    return 0;
+}
+
 // ---- parent store: final tableaux of solved nodes parked in slab slots (warm-started B&B children) ----------
 struct lpx_store {
     int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 128;

@@ -524,3 +524,43 @@ def test_knapsack_expand_in_two_halves_equals_the_batch_call(gpu):
             assert a.node_list(int(ids[j])) == b.node_list(int(ids_b[j])) == {items[j]: vals[j]}
     finally:
         a.close(); b.close()
+
+
+def test_batched_node_assembly_equals_the_per_node_call(gpu):
+    """lpx_tableau_build_nodes (one launch for a group of B&B nodes) against lpx_tableau_build_node node by node: tableau,
+    basis and live shape identical, for nodes of different depths (0 .. 5 branching rows) in handles of one capacity class."""
+    import ctypes as C
+    lib = gpu._lib.lib()
+    g = np.random.default_rng(8)
+    m, n = 9, 14
+    A = g.integers(0, 10, size=(m, n)).astype(float); b = np.floor(0.5 * A.sum(axis=1)); c = g.integers(1, 21, size=n).astype(float)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    R0, C0 = T.shape
+    root = gpu.DeviceTableau.from_host(T, basis)
+    depths = [0, 1, 3, 5, 2]
+    cuts = [[(int(g.integers(0, n)), float(g.choice([1.0, -1.0])), float(g.choice([0.0, -0.0])), float(g.integers(0, 3))) for _ in range(d)] for d in depths]
+    cap = 8
+    one = [gpu.DeviceTableau(R0 + cap, C0 + cap) for _ in depths]
+    many = [gpu.DeviceTableau(R0 + cap, C0 + cap) for _ in depths]
+    try:
+        for t, cs in zip(one, cuts):
+            var = np.array([x[0] for x in cs], np.int32); coef = np.array([x[1] for x in cs]); zero = np.array([x[2] for x in cs]); rhs = np.array([x[3] for x in cs])
+            gpu._lib.check(lib.lpx_tableau_build_node(t._h, root._h, len(cs), var.ctypes.data_as(gpu._lib.ip), coef.ctypes.data_as(gpu._lib.dp),
+                                                      zero.ctypes.data_as(gpu._lib.dp), rhs.ctypes.data_as(gpu._lib.dp)))
+        flat = [x for cs in cuts for x in cs]
+        off = np.cumsum([0] + depths).astype(np.int32)
+        var = np.array([x[0] for x in flat], np.int32); coef = np.array([x[1] for x in flat]); zero = np.array([x[2] for x in flat]); rhs = np.array([x[3] for x in flat])
+        arr = (C.c_void_p * len(many))(*[t._h for t in many])
+        gpu._lib.check(lib.lpx_tableau_build_nodes(arr, root._h, len(many), off.ctypes.data_as(gpu._lib.ip), var.ctypes.data_as(gpu._lib.ip),
+                                                   coef.ctypes.data_as(gpu._lib.dp), zero.ctypes.data_as(gpu._lib.dp), rhs.ctypes.data_as(gpu._lib.dp)))
+        for a, bq, d in zip(one, many, depths):
+            ra, ca, rb_, cb_ = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            gpu._lib.check(lib.lpx_tableau_shape(a._h, C.byref(ra), C.byref(ca), None)); gpu._lib.check(lib.lpx_tableau_shape(bq._h, C.byref(rb_), C.byref(cb_), None))
+            assert (ra.value, ca.value) == (rb_.value, cb_.value) == (R0 + d, C0 + d)
+            a.R, a.C, bq.R, bq.C = ra.value, ca.value, rb_.value, cb_.value
+            Ta, ba = a.download(); Tb, bb = bq.download()
+            assert np.array_equal(Ta.view(np.uint64), Tb.view(np.uint64)) and ba.tolist() == bb.tolist()
+    finally:
+        root.close()
+        for t in one + many:
+            t.close()
