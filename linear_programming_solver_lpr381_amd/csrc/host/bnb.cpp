@@ -398,8 +398,11 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     bool any_warm = false; for (NodeLP* lp : group) if (lp->warm) any_warm = true;
     if (any_warm) {                                               // dual feasible start: only the dual loop (and its clean-up) runs
         dopt.fdf_guard = 0; dopt.cleanup = 1;
-        // a warm-started node needs a few dozen pivots: 64 of them streaming together beat four resident at a time
-        dopt.resident = -1; po.resident = -1;
+        // a warm-started node needs a few dozen pivots: 64 of config 4's 8 MB nodes streaming together beat four resident at a
+        // time; small nodes (dozens to hundreds fit the chip's LDS side by side) stay on the resident kernel
+        size_t node_bytes = 0;
+        for (NodeLP* lp : group) node_bytes = std::max(node_bytes, sizeof(double) * (size_t)lp->R * (size_t)lp->C);
+        if (node_bytes > ((size_t)1 << 20)) { dopt.resident = -1; po.resident = -1; }
     }
     if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
         for (NodeLP* lp : group) {

@@ -12,3 +12,10 @@ for conc in (32, 64, 128, 240):
         r = L.BranchAndBound(bnb_mode=1, bnb_search=1, bnb_dive=1, concurrent_nodes=conc, max_nodes=0).Solve(pb)
         dt = time.perf_counter() - t0
     print(f"slots env={os.environ.get('LPX_GROUP_SLOTS')} conc={conc}: {dt:.2f}s lp={r.LpSolves} nodes/s={r.LpSolves/dt:.0f} z={r.OptimalValue} pivots={r.Stats['pivots']}", flush=True)
+
+for conc in (64, 128):
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = L.BranchAndBound(bnb_mode=1, bnb_search=2, bnb_dive=1, concurrent_nodes=conc, max_nodes=0).Solve(pb)
+        dt = time.perf_counter() - t0
+    print(f"WARM conc={conc}: {dt:.2f}s lp={r.LpSolves} nodes/s={r.LpSolves/dt:.0f} z={r.OptimalValue} pivots={r.Stats['pivots']}", flush=True)
