@@ -170,6 +170,10 @@ int  lpx_store_save_multi(lpx_store** stores, lpx_tableau** ts, int count, int* 
 int  lpx_tableau_build_child_from_store(lpx_tableau* child, lpx_store* s, int slot, int var, int row_of_var,
                                         int is_ge, double bound);
 
+/* The same for a group of children in one launch (child i from stores[i] / slots[i]); returns when they are built. */
+int  lpx_tableau_build_children_from_store(lpx_tableau** children, lpx_store** stores, const int* slots, int count,
+                                           const int32_t* var, const int32_t* row_of_var, const int32_t* is_ge, const double* bound);
+
 /* Branch-and-bound node batches: runs `count` independent tableaux to completion,
  * interleaving their batches on their own streams so that small node LPs overlap on one GPU.
  * dual[i] selects lpx_dual_run (1) or lpx_primal_run (0) semantics; statuses[i] gets each status. */

@@ -165,6 +165,7 @@ def lib() -> C.CDLL:
     L.lpx_multi_solution.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, dp, ip, C.c_int]
     L.lpx_tableau_build_child_from_store.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
     L.lpx_tableau_build_node.argtypes = [vp, vp, C.c_int, ip, dp, dp, dp]
+    L.lpx_tableau_build_children_from_store.argtypes = [C.POINTER(vp), C.POINTER(vp), ip, C.c_int, ip, ip, ip, dp]
     L.lpx_tableau_build_nodes.argtypes = [C.POINTER(vp), vp, C.c_int, ip, ip, dp, dp, dp]
     L.lpx_multi_run.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),
                                 C.POINTER(C.c_int), C.POINTER(Stats)]

@@ -425,10 +425,15 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         {
             const double t0 = PhaseTimer::now();
             std::vector<NodeLP*> assemble[2];                     // cold nodes built on the device, per root template: ONE launch each
+            std::vector<NodeLP*> warm_kids;                       // warm-started children, built from their parked parents: ONE launch
             for (size_t i = a; i < b; ++i) {
                 NodeLP* lp = group[i];
                 if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
-                if (lp->on_device && !lp->warm) {
+                if (lp->warm) {
+                    const int d = lp->depth, w = lp->wslot;
+                    lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));
+                    warm_kids.push_back(lp);
+                } else if (lp->on_device) {
                     const int d = (int)lp->cvar.size(), w = lp->dual ? 1 : 0;
                     lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));   // capacity classes of 32 levels (see upload)
                     assemble[w].push_back(lp);
@@ -445,6 +450,15 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
                     off.push_back((int32_t)var.size());
                 }
                 int rc = lpx_tableau_build_nodes(nh.data(), c.root_tpl[w], (int)nh.size(), off.data(), var.data(), coef.data(), zero.data(), rhs.data());
+                if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            }
+            if (!warm_kids.empty()) {
+                std::vector<lpx_tableau*> ch; std::vector<lpx_store*> st; std::vector<int> slots; std::vector<int32_t> var, row, ge; std::vector<double> bd;
+                for (NodeLP* lp : warm_kids) {
+                    ch.push_back(lp->h); st.push_back(lp->pstore); slots.push_back(lp->pslot);
+                    var.push_back(lp->cvar.back()); row.push_back(lp->prow); ge.push_back(lp->wis_ge ? 1 : 0); bd.push_back(lp->wbound);
+                }
+                int rc = lpx_tableau_build_children_from_store(ch.data(), st.data(), slots.data(), (int)ch.size(), var.data(), row.data(), ge.data(), bd.data());
                 if (rc) throw LpxException(rc, "liblpx: " + last_error());
             }
             g_pt.build += PhaseTimer::now() - t0;

@@ -964,6 +964,50 @@ __global__ __launch_bounds__(256) void lpx_build_child(const double* __restrict_
     T[(size_t)i * ld + j] = v;
 }
 
+// lpx_build_child for a group of children in one launch (blockIdx.z = child); shape and state records written here too
+__global__ __launch_bounds__(256) void lpx_build_children(const ChildDesc* __restrict__ descs)
+{
+    const ChildDesc D = descs[blockIdx.z];
+    const double* __restrict__ Tp = D.Tp; double* __restrict__ T = D.T;
+    const int ldp = D.ldp, Rp = D.Rp, Cp = D.Cp, ld = D.ld, var = D.var, ik = D.ik, is_ge = D.is_ge;
+    const double bound = D.bound;
+    const int mp = Rp - 1, R = Rp + 1, C = Cp + 1;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= R) return;
+    if (i == 0 && blockIdx.x == 0) {
+        if (threadIdx.x == 0) { D.shape[0] = R; D.shape[1] = C; }
+        int32_t* stw = reinterpret_cast<int32_t*>(D.st);
+        for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 256) stw[k] = 0;
+    }
+    if (j == 0 && i < mp) D.basis[i] = D.basis_p[i];
+    if (j == 0 && i == mp) D.basis[mp] = Cp - 1;                    // the new slack column
+    if (j >= ld) return;
+    double v = 0.0;
+    if (j < C) {
+        const int js = (j < Cp - 1) ? j : ((j == C - 1) ? Cp - 1 : -1);   // source column in the parent (-1: new slack)
+        if (i == mp) {                                              // the branching row
+            if (js < 0) v = 1.0;
+            else {
+                const double t = Tp[(size_t)ik * ldp + js];
+                const double e = (js == var) ? 1.0 : 0.0;
+                const double rhs = (js == Cp - 1) ? bound : 0.0;
+                v = is_ge ? ((-e - rhs) + t) : ((e + rhs) - t);     // GE: -e_k + row, rhs -c + x_k ; LE: e_k - row, rhs f - x_k
+            }
+        } else {
+            const int is = (i < mp) ? i : mp;                       // i == mp + 1 is the parent's objective row
+            v = (js < 0) ? 0.0 : Tp[(size_t)is * ldp + js];
+        }
+    }
+    T[(size_t)i * ld + j] = v;
+}
+
+hipError_t launch_build_children(const ChildDesc* descs, int count, int maxld, int maxR, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_build_children, dim3((maxld + 255) / 256, maxR, count), dim3(256), 0, s, descs);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_child(const double* Tp, int ldp, int Rp, int Cp, const int32_t* basis_p, double* T, int ld,
                               int var, int ik, int is_ge, double bound, int32_t* basis, hipStream_t s)
 {

@@ -1089,6 +1089,52 @@ int lpx_tableau_build_child_from_store(lpx_tableau* child, lpx_store* s, int slo
     return 0;
 }
 
+// lpx_tableau_build_child_from_store for a group of children in one launch (child i from stores[i] / slots[i]).
+int lpx_tableau_build_children_from_store(lpx_tableau** children, lpx_store** stores, const int* slots, int count,
+                                          const int32_t* var, const int32_t* row_of_var, const int32_t* is_ge, const double* bound)
+{
+    if (!children || !stores || !slots || count < 0 || (count > 0 && (!var || !row_of_var || !is_ge || !bound))) { set_error("lpx_tableau_build_children_from_store: bad argument"); return LPX_EINVAL; }
+    if (count == 0) return 0;
+    struct Scratch { char* h = nullptr; char* d = nullptr; size_t cap = 0; };
+    static thread_local Scratch sc;             // never freed (see lpx_tableau_build_nodes)
+    const size_t need = sizeof(ChildDesc) * (size_t)count;
+    if (need > sc.cap) {
+        if (sc.h) hipHostFree(sc.h);
+        hipFree(sc.d);
+        sc.h = nullptr; sc.d = nullptr; sc.cap = 0;
+        LPX_HIP_TRY(hipHostMalloc((void**)&sc.h, 2 * need));
+        LPX_HIP_TRY(hipMalloc((void**)&sc.d, 2 * need));
+        sc.cap = 2 * need;
+    }
+    int maxld = 16, maxR = 1;
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* ch = children[i]; lpx_store* s = stores[i]; const int slot = slots[i];
+        if (!ch || !s || slot < 0 || slot >= (int)s->R.size()) { set_error("lpx_tableau_build_children_from_store: bad child / store / slot"); return LPX_EINVAL; }
+        const int Rp = s->R[slot], Cp = s->C[slot];
+        if (var[i] < 0 || var[i] >= Cp - 1 || row_of_var[i] < 0 || row_of_var[i] >= Rp - 1) { set_error("lpx_tableau_build_children_from_store: variable / row out of range"); return LPX_EINVAL; }
+        if (Rp + 1 > ch->Rcap || Cp + 1 > ch->Ccap) { set_error("lpx_tableau_build_children_from_store: child handle too small"); return LPX_EINVAL; }
+        maxld = std::max(maxld, ch->ld); maxR = std::max(maxR, Rp + 1);
+    }
+    for (int i = 0; i < count; ++i) {           // every child's own stream has to be idle before another stream writes its tableau
+        bool seen = false; for (int j = 0; j < i; ++j) if (children[j]->stream == children[i]->stream) { seen = true; break; }
+        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(children[i]->stream));
+    }
+    ChildDesc* d = reinterpret_cast<ChildDesc*>(sc.h);
+    for (int i = 0; i < count; ++i) {
+        lpx_tableau* ch = children[i]; lpx_store* s = stores[i]; const int slot = slots[i];
+        const int Rp = s->R[slot], Cp = s->C[slot];
+        ch->R = Rp + 1; ch->C = Cp + 1; ch->shape_h[0] = ch->R; ch->shape_h[1] = ch->C;
+        d[i].Tp = store_T(s, slot); d[i].basis_p = store_b(s, slot); d[i].T = ch->T; d[i].basis = ch->basis; d[i].shape = ch->shape; d[i].st = ch->st;
+        d[i].ldp = s->ld; d[i].Rp = Rp; d[i].Cp = Cp; d[i].ld = ch->ld; d[i].var = var[i]; d[i].ik = row_of_var[i]; d[i].is_ge = is_ge[i] ? 1 : 0; d[i].pad = 0;
+        d[i].bound = bound[i];
+    }
+    hipStream_t st = children[0]->stream;
+    LPX_HIP_TRY(hipMemcpyAsync(sc.d, sc.h, need, hipMemcpyHostToDevice, st));
+    LPX_HIP_TRY(launch_build_children(reinterpret_cast<const ChildDesc*>(sc.d), count, maxld, maxR, st));
+    LPX_HIP_TRY(hipStreamSynchronize(st));      // the runs that follow use other streams
+    return 0;
+}
+
 int lpx_tableau_build_child(lpx_tableau* child, lpx_tableau* parent, int var, int row_of_var, int is_ge, double bound)
 {
     if (!child || !parent || child == parent) { set_error("lpx_tableau_build_child: bad argument"); return LPX_EINVAL; }

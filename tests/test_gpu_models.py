@@ -474,6 +474,7 @@ def test_batched_solution_readback_and_parking_equal_the_per_node_calls(gpu):
         stores = (C.c_void_p * count)(*[store] * count)
         gpu._lib.check(lib.lpx_store_save_multi(stores, arr, count, slots))
         assert len(set(slots)) == count
+        singles = []
         for k, t in enumerate(ts):
             one = C.c_int(-1)
             gpu._lib.check(lib.lpx_store_save(store, t._h, C.byref(one)))
@@ -488,6 +489,18 @@ def test_batched_solution_readback_and_parking_equal_the_per_node_calls(gpu):
                 ch.R, ch.C = R + 1, Cc + 1
                 kids.append(ch.download()); ch.close()
             assert np.array_equal(kids[0][0].view(np.uint64), kids[1][0].view(np.uint64)) and kids[0][1].tolist() == kids[1][1].tolist()
+            singles.append((kids[0], int(b0[row]), row, float(np.floor(T0[row, -1]))))
+        # ... and the children of all nodes in ONE launch (lpx_tableau_build_children_from_store)
+        chs = [gpu.DeviceTableau(R + 1, Cc + 1) for _ in ts]
+        carr = (C.c_void_p * count)(*[t._h for t in chs])
+        var = np.array([x[1] for x in singles], np.int32); rowv = np.array([x[2] for x in singles], np.int32)
+        ge = np.zeros(count, np.int32); bd = np.array([x[3] for x in singles])
+        gpu._lib.check(lib.lpx_tableau_build_children_from_store(carr, stores, slots, count, var.ctypes.data_as(gpu._lib.ip), rowv.ctypes.data_as(gpu._lib.ip),
+                                                                 ge.ctypes.data_as(gpu._lib.ip), bd.ctypes.data_as(gpu._lib.dp)))
+        for ch, (ref, _, _, _) in zip(chs, singles):
+            ch.R, ch.C = R + 1, Cc + 1
+            Tc, bc = ch.download(); ch.close()
+            assert np.array_equal(Tc.view(np.uint64), ref[0].view(np.uint64)) and bc.tolist() == ref[1].tolist()
     finally:
         lib.lpx_store_destroy(store)
         for t in ts:
