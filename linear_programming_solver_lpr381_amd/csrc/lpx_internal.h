@@ -65,6 +65,8 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
 hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int select_mb_blocks(int C);
+hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);
+hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s,
                              int maxR, int maxC);       // capacity of the largest node: sizes the dual select's LDS
 hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s);

@@ -1165,6 +1165,30 @@ hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_
     }
     return hipGetLastError();
 }
+// state records of a whole group in one launch each way (pinned host array <-> every node's device record): a group of 64
+// nodes paid 64 small copies per begin and per poll
+__global__ __launch_bounds__(64) void lpx_states_scatter(const SelParams* __restrict__ arr, const DevState* __restrict__ src)
+{
+    const int32_t* s = reinterpret_cast<const int32_t*>(src + blockIdx.x);
+    int32_t* d = reinterpret_cast<int32_t*>(arr[blockIdx.x].st);
+    for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 64) d[k] = s[k];
+}
+__global__ __launch_bounds__(64) void lpx_states_gather(const SelParams* __restrict__ arr, DevState* __restrict__ dst)
+{
+    const int32_t* s = reinterpret_cast<const int32_t*>(arr[blockIdx.x].st);
+    int32_t* d = reinterpret_cast<int32_t*>(dst + blockIdx.x);
+    for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 64) d[k] = s[k];
+}
+hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_states_scatter, dim3(count), dim3(64), 0, s, arr, src_pinned);
+    return hipGetLastError();
+}
+hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_states_gather, dim3(count), dim3(64), 0, s, arr, dst_pinned);
+    return hipGetLastError();
+}
 hipError_t launch_group_init(const SelParams* arr, int count, hipStream_t s)
 {
     hipLaunchKernelGGL(lpx_la_init_b, dim3(1, count), dim3(SEL_NT), 0, s, arr);

@@ -714,9 +714,9 @@ int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevS
             init.fdf_count = s0.fdf_count; init.dual_iter = s0.dual_iter; init.primal_count = s0.primal_count;
         }
         g.hs[k] = init;
-        LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[k], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
     }
     LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(SelParams) * K, hipMemcpyHostToDevice, g.stream));
+    LPX_HIP_TRY(launch_states_scatter(g.d, g.hs, K, g.stream));      // every node's initial state record, one launch
     if (!r.dual) LPX_HIP_TRY(launch_group_init(g.d, K, g.stream));
     else LPX_HIP_TRY(launch_group_rhs_init(g.d, K, g.stream));
     // graph of `batch` iterations, keyed by everything baked into the launches
@@ -748,8 +748,8 @@ int group_submit(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o)
     if (o->use_graph && g.gexec) LPX_HIP_TRY(hipGraphLaunch(g.gexec, g.stream));
     else for (int i = 0; i < r.batch; ++i) LPX_HIP_TRY(launch_group_iter(g.d, K, r.dual, r.max_nblk, r.max_blocks, g.stream, r.maxR, r.maxC));
     r.enq += r.batch;
-    for (int k = 0; k < K; ++k)
-        LPX_HIP_TRY(hipMemcpyAsync(&g.hs[k], ts[r.idx[k]]->st, sizeof(DevState), hipMemcpyDeviceToHost, g.stream));
+    (void)ts;
+    LPX_HIP_TRY(launch_states_gather(g.d, g.hs, K, g.stream));       // every node's state record into the pinned array, one launch
     return 0;
 }
 
