@@ -180,6 +180,11 @@ int  lpx_tableau_build_children_from_store(lpx_tableau** children, lpx_store** s
 int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
                   const lpx_run_opts* dual_opts, int* statuses, lpx_stats* stats /* [count] or NULL */);
 
+/* The same for a rolling batch: returns as soon as at most `min_active` runs are unfinished and reports those as LPX_RUNNING;
+ * handed in again (with fresh tableaux beside them) they continue where they stopped.  Batched streaming kernels only. */
+int lpx_multi_run_some(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
+                       const lpx_run_opts* dual_opts, int* statuses, lpx_stats* stats /* [count] or NULL */, int min_active);
+
 /* ---- one-shot entry points on host buffers (what the C# shim binds) -------------------------- */
 /* Replaces the loop of PrimalSimplex.Solve (Models/PrimalSimplex.cs:92-124) on the `double[,]`
  * built by BuildTableau (:179-203).  T and basis are updated in place. */

@@ -396,13 +396,18 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
     bool any_warm = false; for (NodeLP* lp : group) if (lp->warm) any_warm = true;
+    bool rolling = false;
     if (any_warm) {                                               // dual feasible start: only the dual loop (and its clean-up) runs
         dopt.fdf_guard = 0; dopt.cleanup = 1;
         // a warm-started node needs a few dozen pivots: 64 of config 4's 8 MB nodes streaming together beat four resident at a
         // time; small nodes (dozens to hundreds fit the chip's LDS side by side) stay on the resident kernel
         size_t node_bytes = 0;
         for (NodeLP* lp : group) node_bytes = std::max(node_bytes, sizeof(double) * (size_t)lp->R * (size_t)lp->C);
-        if (node_bytes > ((size_t)1 << 20)) { dopt.resident = -1; po.resident = -1; }
+        if (node_bytes > ((size_t)1 << 20)) {
+            dopt.resident = -1; po.resident = -1; rolling = group.size() > 1;
+            static const int roll_batch = [] { const char* e = std::getenv("LPX_ROLL_BATCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();   // pivots between polls
+            if (rolling && c.opt.batch <= 0) dopt.batch = po.batch = roll_batch;
+        }
     }
     if (c.opt.test_node_lp) {          // test seam (include/lpx.h): the device loop is stood in for
         for (NodeLP* lp : group) {
@@ -419,52 +424,89 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         return;
     }
     const size_t width = (size_t)std::max(1, c.opt.concurrent_nodes);
+    // gives every node of `nodes` a handle and builds its tableau on the device (one launch per kind); returns the admitted ones
+    auto admit = [&](const std::vector<NodeLP*>& nodes, std::vector<NodeLP*>& live) {
+        const double t0 = PhaseTimer::now();
+        std::vector<NodeLP*> assemble[2];                     // cold nodes built on the device, per root template: ONE launch each
+        std::vector<NodeLP*> warm_kids;                       // warm-started children, built from their parked parents: ONE launch
+        for (NodeLP* lp : nodes) {
+            if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
+            if (lp->warm) {
+                const int d = lp->depth, w = lp->wslot;
+                lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));
+                warm_kids.push_back(lp);
+            } else if (lp->on_device) {
+                const int d = (int)lp->cvar.size(), w = lp->dual ? 1 : 0;
+                lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));   // capacity classes of 32 levels (see upload)
+                assemble[w].push_back(lp);
+            } else upload(c, *lp);
+            live.push_back(lp);
+        }
+        for (int w = 0; w < 2; ++w) {
+            if (assemble[w].empty()) continue;
+            std::vector<lpx_tableau*> nh; std::vector<int32_t> off{0}, var; std::vector<double> coef, zero, rhs;
+            for (NodeLP* lp : assemble[w]) {
+                nh.push_back(lp->h);
+                var.insert(var.end(), lp->cvar.begin(), lp->cvar.end()); coef.insert(coef.end(), lp->ccoef.begin(), lp->ccoef.end());
+                zero.insert(zero.end(), lp->czero.begin(), lp->czero.end()); rhs.insert(rhs.end(), lp->crhs.begin(), lp->crhs.end());
+                off.push_back((int32_t)var.size());
+            }
+            int rc = lpx_tableau_build_nodes(nh.data(), c.root_tpl[w], (int)nh.size(), off.data(), var.data(), coef.data(), zero.data(), rhs.data());
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        }
+        if (!warm_kids.empty()) {
+            std::vector<lpx_tableau*> ch; std::vector<lpx_store*> st; std::vector<int> slots; std::vector<int32_t> var, row, ge; std::vector<double> bd;
+            for (NodeLP* lp : warm_kids) {
+                ch.push_back(lp->h); st.push_back(lp->pstore); slots.push_back(lp->pslot);
+                var.push_back(lp->cvar.back()); row.push_back(lp->prow); ge.push_back(lp->wis_ge ? 1 : 0); bd.push_back(lp->wbound);
+            }
+            int rc = lpx_tableau_build_children_from_store(ch.data(), st.data(), slots.data(), (int)ch.size(), var.data(), row.data(), ge.data(), bd.data());
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+        }
+        g_pt.build += PhaseTimer::now() - t0;
+    };
+    if (rolling) {
+        // ROLLING batch (warm-started children on the streaming kernels): most of them need a few dozen pivots, a few need hundreds.
+        // A run stops when only half of the batch is still going (lpx_multi_run_some, polled every 32 pivots); those stay, fresh nodes fill the
+        // batch up, and nobody waits at the per-step latency floor for the slowest node of a fixed batch.
+        size_t next = 0;
+        std::vector<NodeLP*> inflight;
+        while (next < group.size() || !inflight.empty()) {
+            std::vector<NodeLP*> fresh;
+            while (next < group.size() && inflight.size() + fresh.size() < width) fresh.push_back(group[next++]);
+            if (c.count_work) c.out->LpSolves += (int64_t)fresh.size();
+            admit(fresh, inflight);
+            if (inflight.empty()) continue;
+            std::vector<lpx_tableau*> hs; std::vector<int> dual;
+            for (NodeLP* lp : inflight) { hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); }
+            std::vector<int> st(hs.size()); std::vector<lpx_stats> ss(hs.size());
+            static const int roll_div = [] { const char* e = std::getenv("LPX_ROLL_DIV"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2; }();   // diagnostic
+            const int min_active = next < group.size() ? (int)std::max<size_t>(1, width / roll_div) : 0;
+            double t0 = PhaseTimer::now();
+            int rc = lpx_multi_run_some(hs.data(), dual.data(), (int)hs.size(), &po, &dopt, st.data(), ss.data(), min_active);
+            g_pt.run += PhaseTimer::now() - t0;
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            std::vector<NodeLP*> fin, keep; std::vector<int> fst; std::vector<lpx_stats> fss;
+            for (size_t i = 0; i < inflight.size(); ++i) {
+                if (st[i] == LPX_RUNNING) keep.push_back(inflight[i]);
+                else { fin.push_back(inflight[i]); fst.push_back(st[i]); fss.push_back(ss[i]); }
+            }
+            // pivots are cumulative per node: count a node's once, when it finishes
+            t0 = PhaseTimer::now();
+            collect_group(c, fin, fst, fss, nvars);
+            g_pt.collect += PhaseTimer::now() - t0;
+            inflight.swap(keep);
+        }
+        return;
+    }
     for (size_t a = 0; a < group.size(); a += width) {
         const size_t b = std::min(group.size(), a + width);
-        std::vector<lpx_tableau*> hs; std::vector<int> dual; std::vector<NodeLP*> live;
-        {
-            const double t0 = PhaseTimer::now();
-            std::vector<NodeLP*> assemble[2];                     // cold nodes built on the device, per root template: ONE launch each
-            std::vector<NodeLP*> warm_kids;                       // warm-started children, built from their parked parents: ONE launch
-            for (size_t i = a; i < b; ++i) {
-                NodeLP* lp = group[i];
-                if (lp->error || lp->R < 2) { if (lp->R < 2) lp->error = true; continue; }
-                if (lp->warm) {
-                    const int d = lp->depth, w = lp->wslot;
-                    lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));
-                    warm_kids.push_back(lp);
-                } else if (lp->on_device) {
-                    const int d = (int)lp->cvar.size(), w = lp->dual ? 1 : 0;
-                    lp->h = c.pool.get(c.tplR[w] + cap_slack(d), c.tplC[w] + cap_slack(d));   // capacity classes of 32 levels (see upload)
-                    assemble[w].push_back(lp);
-                } else upload(c, *lp);
-                hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); live.push_back(lp);
-            }
-            for (int w = 0; w < 2; ++w) {
-                if (assemble[w].empty()) continue;
-                std::vector<lpx_tableau*> nh; std::vector<int32_t> off{0}, var; std::vector<double> coef, zero, rhs;
-                for (NodeLP* lp : assemble[w]) {
-                    nh.push_back(lp->h);
-                    var.insert(var.end(), lp->cvar.begin(), lp->cvar.end()); coef.insert(coef.end(), lp->ccoef.begin(), lp->ccoef.end());
-                    zero.insert(zero.end(), lp->czero.begin(), lp->czero.end()); rhs.insert(rhs.end(), lp->crhs.begin(), lp->crhs.end());
-                    off.push_back((int32_t)var.size());
-                }
-                int rc = lpx_tableau_build_nodes(nh.data(), c.root_tpl[w], (int)nh.size(), off.data(), var.data(), coef.data(), zero.data(), rhs.data());
-                if (rc) throw LpxException(rc, "liblpx: " + last_error());
-            }
-            if (!warm_kids.empty()) {
-                std::vector<lpx_tableau*> ch; std::vector<lpx_store*> st; std::vector<int> slots; std::vector<int32_t> var, row, ge; std::vector<double> bd;
-                for (NodeLP* lp : warm_kids) {
-                    ch.push_back(lp->h); st.push_back(lp->pstore); slots.push_back(lp->pslot);
-                    var.push_back(lp->cvar.back()); row.push_back(lp->prow); ge.push_back(lp->wis_ge ? 1 : 0); bd.push_back(lp->wbound);
-                }
-                int rc = lpx_tableau_build_children_from_store(ch.data(), st.data(), slots.data(), (int)ch.size(), var.data(), row.data(), ge.data(), bd.data());
-                if (rc) throw LpxException(rc, "liblpx: " + last_error());
-            }
-            g_pt.build += PhaseTimer::now() - t0;
-        }
+        std::vector<NodeLP*> live;
+        admit(std::vector<NodeLP*>(group.begin() + a, group.begin() + b), live);
         if (c.count_work) c.out->LpSolves += (int64_t)(b - a);        // every node reaches _solver.Solve (:148), even if it throws
-        if (hs.empty()) continue;
+        if (live.empty()) continue;
+        std::vector<lpx_tableau*> hs; std::vector<int> dual;
+        for (NodeLP* lp : live) { hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); }
         std::vector<int> st(hs.size()); std::vector<lpx_stats> ss(hs.size());
         double t0 = PhaseTimer::now();
         int rc = lpx_multi_run(hs.data(), dual.data(), (int)hs.size(), &po, &dopt, st.data(), ss.data());

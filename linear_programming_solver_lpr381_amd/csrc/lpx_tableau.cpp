@@ -34,6 +34,7 @@ struct lpx_tableau {
     int trace_cap = 0;
     DevState* st = nullptr;     // device
     DevState* hst = nullptr;    // pinned host mirror
+    bool suspended = false;     // lpx_multi_run_some left this run unfinished: *hst is where it continues
     int32_t* frows = nullptr; int32_t* fcols = nullptr; int32_t* fchosen = nullptr; int fcap = 0;
     char* cutbuf = nullptr; char* cutbuf_h = nullptr; int cutcap = 0;   // staging of branching-row descriptors
     hipStream_t stream = nullptr;
@@ -199,6 +200,7 @@ int lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld)
 int lpx_tableau_upload(lpx_tableau* t, const double* T, const int32_t* basis)
 {
     if (!t || !T) { set_error("lpx_tableau_upload: null argument"); return LPX_EINVAL; }
+    t->suspended = false;
     LPX_HIP_TRY(hipMemcpy2DAsync(t->T, sizeof(double) * t->ld, T, sizeof(double) * t->C,
                                  sizeof(double) * t->C, t->R, hipMemcpyHostToDevice, t->stream));
     if (basis && t->R > 1)
@@ -685,6 +687,7 @@ int group_reserve(GroupBuf& g, int count)
 struct GroupRun {
     GroupBuf* g = nullptr; std::vector<int> idx; int dual = 0; int batch = 64; long long budget = 0, enq = 0;
     int max_nblk = 1, max_blocks = 1, maxR = 2, maxC = 2; bool done = true;
+    int min_active = 0; bool suspended_exit = false;     // stop (without exhausting the budget) once this few nodes are still running
 };
 
 int group_begin(GroupRun& r, lpx_tableau** ts, const lpx_run_opts* o, const DevState* inits = nullptr)
@@ -757,19 +760,20 @@ int group_complete(GroupRun& r)
 {
     GroupBuf& g = *r.g;
     LPX_HIP_TRY(hipStreamSynchronize(g.stream));
-    bool all = true;
-    for (size_t k = 0; k < r.idx.size(); ++k) if (g.hs[k].status == LPX_RUNNING) { all = false; break; }
-    r.done = all || r.enq >= r.budget;
+    int running = 0;
+    for (size_t k = 0; k < r.idx.size(); ++k) if (g.hs[k].status == LPX_RUNNING) ++running;
+    r.done = running == 0 || r.enq >= r.budget;
+    if (!r.done && r.min_active > 0 && running <= r.min_active) { r.done = true; r.suspended_exit = true; }
     return 0;
 }
 
 }  // namespace
 
 static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
-                             const lpx_run_opts* dopts, int* statuses, lpx_stats* stats, const DevState* inits = nullptr)
+                             const lpx_run_opts* dopts, int* statuses, lpx_stats* stats, const DevState* inits = nullptr, int min_active = 0)
 {
     GroupRun runs[2];
-    for (int w = 0; w < 2; ++w) { runs[w].g = &g_groups[w]; runs[w].dual = w; }
+    for (int w = 0; w < 2; ++w) { runs[w].g = &g_groups[w]; runs[w].dual = w; runs[w].min_active = min_active; }
     for (int i = 0; i < count; ++i) runs[dual[i] ? 1 : 0].idx.push_back(i);
     const double t0 = now_ms();
     for (int w = 0; w < 2; ++w) if (!runs[w].idx.empty()) { int rc = group_begin(runs[w], ts, w ? dopts : popts, inits); if (rc) return rc; }
@@ -786,7 +790,8 @@ static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const
             const DevState& s = r.g->hs[k];
             const int i = r.idx[k];
             *ts[i]->hst = s;
-            statuses[i] = s.status == LPX_RUNNING ? LPX_ITER_LIMIT : s.status;
+            statuses[i] = s.status == LPX_RUNNING ? (r.suspended_exit ? LPX_RUNNING : LPX_ITER_LIMIT) : s.status;
+            ts[i]->suspended = statuses[i] == LPX_RUNNING;          // continues from *hst in the next lpx_multi_run_some
             if (stats) {
                 std::memset(&stats[i], 0, sizeof(lpx_stats));
                 stats[i].pivots = s.iter; stats[i].fdf_pivots = s.fdf_count;
@@ -917,7 +922,7 @@ int lpx_tableau_set_shape(lpx_tableau* t, int R, int C)
 {
     if (!t || R < 1 || C < 2 || R > t->Rcap || C > t->Ccap) { set_error("lpx_tableau_set_shape: shape outside the handle's capacity"); return LPX_EINVAL; }
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));          // the pinned staging word may still be in flight
-    t->R = R; t->C = C;
+    t->R = R; t->C = C; t->suspended = false;               // a new tableau is coming: nothing to continue
     t->shape_h[0] = R; t->shape_h[1] = C;
     LPX_HIP_TRY(hipMemcpyAsync(t->shape, t->shape_h, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
     return 0;
@@ -998,7 +1003,7 @@ int lpx_tableau_build_nodes(lpx_tableau** nodes, const lpx_tableau* root, int co
     for (int i = 0; i < count; ++i) {
         lpx_tableau* t = nodes[i];
         const int nc = cut_off[i + 1] - cut_off[i];
-        t->R = root->R + nc; t->C = root->C + nc;
+        t->R = root->R + nc; t->C = root->C + nc; t->suspended = false;
         t->shape_h[0] = t->R; t->shape_h[1] = t->C;
         d[i].T = t->T; d[i].basis = t->basis; d[i].shape = t->shape; d[i].st = t->st; d[i].ld = t->ld; d[i].R = t->R; d[i].C = t->C; d[i].cut0 = cut_off[i];
     }
@@ -1123,7 +1128,7 @@ int lpx_tableau_build_children_from_store(lpx_tableau** children, lpx_store** st
     for (int i = 0; i < count; ++i) {
         lpx_tableau* ch = children[i]; lpx_store* s = stores[i]; const int slot = slots[i];
         const int Rp = s->R[slot], Cp = s->C[slot];
-        ch->R = Rp + 1; ch->C = Cp + 1; ch->shape_h[0] = ch->R; ch->shape_h[1] = ch->C;
+        ch->R = Rp + 1; ch->C = Cp + 1; ch->suspended = false; ch->shape_h[0] = ch->R; ch->shape_h[1] = ch->C;
         d[i].Tp = store_T(s, slot); d[i].basis_p = store_b(s, slot); d[i].T = ch->T; d[i].basis = ch->basis; d[i].shape = ch->shape; d[i].st = ch->st;
         d[i].ldp = s->ld; d[i].Rp = Rp; d[i].Cp = Cp; d[i].ld = ch->ld; d[i].var = var[i]; d[i].ik = row_of_var[i]; d[i].is_ge = is_ge[i] ? 1 : 0; d[i].pad = 0;
         d[i].bound = bound[i];
@@ -1345,6 +1350,38 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
         }
     }
     return 0;
+}
+
+// lpx_multi_run for a ROLLING batch (warm-started B&B children need a few dozen pivots each, a few of them hundreds): the run
+// stops as soon as at most `min_active` nodes are still running and reports them as LPX_RUNNING; the caller hands them in again
+// together with fresh nodes and they continue where they stopped (pivot count, phase, counters: the handle remembers).  Without
+// it a batch of 64 runs as long as its slowest node while the device idles at the per-step latency floor.  Streaming batched
+// kernels only (callers that want the resident group kernel use lpx_multi_run); min_active = 0 runs everything to the end.
+int lpx_multi_run_some(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
+                       int* statuses, lpx_stats* stats, int min_active)
+{
+    if (!ts || !dual || count < 0 || !statuses) { set_error("lpx_multi_run_some: bad argument"); return LPX_EINVAL; }
+    lpx_run_opts pd, dd;
+    if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
+    if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
+    bool ok = count >= 1 && !popts->profile && !dopts->profile, resumed = false;
+    for (int i = 0; i < count; ++i) {
+        if (!ts[i] || ts[i]->R < 2) { set_error("lpx_multi_run_some: null or empty tableau"); return LPX_EINVAL; }
+        if (!dual[i] && !ts[i]->us) ok = false;
+        if (ts[i]->suspended) resumed = true;
+    }
+    if (!ok) {
+        if (resumed) { set_error("lpx_multi_run_some: a suspended run cannot continue on this path"); return LPX_EINVAL; }
+        return lpx_multi_run(ts, dual, count, popts, dopts, statuses, stats);
+    }
+    std::vector<DevState> inits(count);
+    for (int i = 0; i < count; ++i) {
+        DevState z; std::memset(&z, 0, sizeof(z));
+        z.status = LPX_RUNNING; z.phase = dual[i] ? 0 : 2;
+        inits[i] = ts[i]->suspended ? *ts[i]->hst : z;
+        ts[i]->suspended = false;
+    }
+    return multi_run_batched(ts, dual, count, popts, dopts, statuses, stats, inits.data(), min_active < count ? min_active : 0);
 }
 
 int lpx_primal_tableau(double* T, int R, int C, int32_t* basis, double eps, int max_iter,
