@@ -577,3 +577,102 @@ def test_batched_node_assembly_equals_the_per_node_call(gpu):
         root.close()
         for t in one + many:
             t.close()
+
+
+def test_rolling_batches_suspend_and_continue_bitwise(gpu, oracle):
+    """lpx_multi_run_some: a run that returns while some tableaux are still going (LPX_RUNNING = 4), handed in again beside
+    fresh tableaux, ends in the same tableaux -- bit for bit -- as the oracle's solve of each LP; pivot counts are cumulative."""
+    import ctypes as C
+    lib = gpu._lib.lib()
+    g = np.random.default_rng(21)
+    lps = []
+    for k in range(14):
+        m, n = int(g.integers(20, 90)), int(g.integers(30, 120))
+        c, A, b = g.uniform(0.5, 1.5, n), g.random((m, n)), 0.5 * n * g.uniform(0.9, 1.1, m)
+        lps.append(synth.primal_tableau_from(c, A, b))
+    refs = []
+    for T, basis in lps:
+        Tr, br = T.copy(), basis.copy()
+        st, tr = oracle.primal_tableau(Tr, br)
+        refs.append((st, len(tr), Tr, br))
+    assert len({r[1] for r in refs}) > 4                             # different lengths: some finish early, some late
+    ts = [gpu.DeviceTableau.from_host(T, basis) for T, basis in lps]
+    po = gpu._lib.default_opts(False, resident=-1, batch=8); do = gpu._lib.default_opts(True, resident=-1, batch=8)
+    try:
+        waiting, inflight, done, calls, suspended_seen = list(range(len(ts))), [], {}, 0, 0
+        while waiting or inflight:
+            while waiting and len(inflight) < 6:
+                inflight.append(waiting.pop(0))
+            k = len(inflight)
+            hs = (C.c_void_p * k)(*[ts[i]._h for i in inflight]); dl = (C.c_int * k)(*([0] * k))
+            st = (C.c_int * k)(); ss = (gpu._lib.Stats * k)()
+            gpu._lib.check(lib.lpx_multi_run_some(hs, dl, k, C.byref(po), C.byref(do), st, ss, 3 if waiting else 0))
+            calls += 1
+            keep = []
+            for j, i in enumerate(inflight):
+                if st[j] == 4:
+                    keep.append(i); suspended_seen += 1
+                else:
+                    done[i] = (st[j], ss[j].pivots)
+            inflight = keep
+            assert calls < 200
+        assert suspended_seen > 0                                       # the suspension path did run
+        for i, t in enumerate(ts):
+            Tg, bg = t.download()
+            st_ref, piv_ref, Tr, br = refs[i]
+            assert done[i] == (st_ref, piv_ref), i
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist(), i
+    finally:
+        for t in ts:
+            t.close()
+
+
+def test_rolling_batches_dual_phase_machine_survives_suspension(gpu, oracle):
+    """The same through the dual path (ForceDualFeasibility -> dual loop -> repaired clean-up, Models/DualSimplex.cs:24,36-113):
+    a run suspended in any phase continues in that phase with its counters; tableaux, bases, statuses and the
+    ForceDualFeasibility pivot counts equal the oracle's."""
+    import ctypes as C
+    lib = gpu._lib.lib()
+    cases = [(20, 30, 2, 5), (40, 64, 3, 10), (64, 100, 4, 7), (100, 160, 5, 30), (30, 50, 6, 8), (80, 90, 7, 20), (50, 120, 8, 12), (90, 140, 9, 25)]
+    lps, refs = [], []
+    for (m, n, seed, n_ge) in cases:
+        c, A, b = synth.dense_lp(m, n, seed=seed)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        g = np.random.Generator(np.random.PCG64(seed + 99))
+        for i in g.choice(m, size=n_ge, replace=False):
+            T[i, :n] *= -1.0
+            T[i, -1] = -0.02 * T[i, -1]
+        lps.append((T, basis))
+        Tr, br = T.copy(), basis.copy()
+        st, tr, nfdf = oracle.dual_tableau(Tr, br, fdf_guard=10000, cleanup=1)
+        refs.append((st, len(tr), nfdf, Tr, br))
+    ts = [gpu.DeviceTableau.from_host(T, basis) for T, basis in lps]
+    po = gpu._lib.default_opts(False, resident=-1, batch=4)
+    do = gpu._lib.default_opts(True, resident=-1, batch=4, fdf_guard=10000, cleanup=1)
+    try:
+        waiting, inflight, done, calls, suspended_seen = list(range(len(ts))), [], {}, 0, 0
+        while waiting or inflight:
+            while waiting and len(inflight) < 4:
+                inflight.append(waiting.pop(0))
+            k = len(inflight)
+            hs = (C.c_void_p * k)(*[ts[i]._h for i in inflight]); dl = (C.c_int * k)(*([1] * k))
+            st = (C.c_int * k)(); ss = (gpu._lib.Stats * k)()
+            gpu._lib.check(lib.lpx_multi_run_some(hs, dl, k, C.byref(po), C.byref(do), st, ss, 2 if waiting else 0))
+            calls += 1
+            keep = []
+            for j, i in enumerate(inflight):
+                if st[j] == 4:
+                    keep.append(i); suspended_seen += 1
+                else:
+                    done[i] = (st[j], ss[j].pivots, ss[j].fdf_pivots)
+            inflight = keep
+            assert calls < 2000
+        assert suspended_seen > 0
+        for i, t in enumerate(ts):
+            Tg, bg = t.download()
+            st_ref, piv_ref, nfdf_ref, Tr, br = refs[i]
+            assert done[i] == (st_ref, piv_ref, nfdf_ref), (i, done[i], (st_ref, piv_ref, nfdf_ref))
+            assert np.array_equal(Tg.view(np.uint64), Tr.view(np.uint64)) and bg.tolist() == br.tolist(), i
+    finally:
+        for t in ts:
+            t.close()
