@@ -79,6 +79,8 @@ hipError_t launch_build_nodes(const double* T0, int ld0, int R0, int C0, const B
 struct ChildDesc { const double* Tp; const int32_t* basis_p; double* T; int32_t* basis; int32_t* shape; DevState* st;
                    int ldp, Rp, Cp, ld, var, ik, is_ge, pad; double bound; };
 hipError_t launch_build_children(const ChildDesc* descs, int count, int maxld, int maxR, hipStream_t s);
+struct ParkDesc { const double* srcT; double* dstT; const int32_t* srcB; int32_t* dstB; size_t doubles; int m, pad; };
+hipError_t launch_park_many(const ParkDesc* descs, int count, int blocks_per_node, hipStream_t s);
 struct GatherDesc { const double* T; const int32_t* basis; int ld, R, C, off; };
 int update_policy(int ld, int R);            // 0 = cache-resident update kernel, 1 = all-nt streaming, 2 = mixed-store streaming
 hipError_t launch_gather_solution(const GatherDesc* descs, int count, double* out_rhs, int32_t* out_basis, hipStream_t s);

@@ -1165,6 +1165,22 @@ hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_
     }
     return hipGetLastError();
 }
+// parent parking for a whole group: every finished node's tableau and basis into its store slot, one launch
+__global__ __launch_bounds__(256) void lpx_park_many(const ParkDesc* __restrict__ descs)
+{
+    const ParkDesc D = descs[blockIdx.y];
+    const size_t n2 = D.doubles / 2;                                  // leading dimensions are multiples of 16: whole double2s
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(D.srcT);
+    double2* __restrict__ dst = reinterpret_cast<double2*>(D.dstT);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < D.m; i += 256) D.dstB[i] = D.srcB[i];
+}
+hipError_t launch_park_many(const ParkDesc* descs, int count, int blocks_per_node, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_park_many, dim3(blocks_per_node, count), dim3(256), 0, s, descs);
+    return hipGetLastError();
+}
+
 // state records of a whole group in one launch each way (pinned host array <-> every node's device record): a group of 64
 // nodes paid 64 small copies per begin and per poll
 __global__ __launch_bounds__(64) void lpx_states_scatter(const SelParams* __restrict__ arr, const DevState* __restrict__ src)

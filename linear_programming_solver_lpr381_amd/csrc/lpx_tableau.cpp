@@ -1239,11 +1239,29 @@ int lpx_multi_solution(lpx_tableau** ts, int count, int nvars, double* x, double
 int lpx_store_save_multi(lpx_store** ss, lpx_tableau** ts, int count, int* slots)
 {
     if (!ss || !ts || !slots || count < 0) { set_error("lpx_store_save_multi: bad argument"); return LPX_EINVAL; }
+    if (count == 0) return 0;
     for (int i = 0; i < count; ++i) {
         lpx_store* s = ss[i]; lpx_tableau* t = ts[i];
         if (!s || !t) { set_error("lpx_store_save_multi: null argument"); return LPX_EINVAL; }
         if (t->ld != s->ld || t->R > s->Rcap) { set_error("lpx_store_save_multi: tableau does not match the store's capacity class"); return LPX_EINVAL; }
     }
+    struct Scratch { char* h = nullptr; char* d = nullptr; size_t cap = 0; };
+    static thread_local Scratch sc;             // never freed (see lpx_tableau_build_nodes)
+    const size_t need = sizeof(ParkDesc) * (size_t)count;
+    if (need > sc.cap) {
+        if (sc.h) hipHostFree(sc.h);
+        hipFree(sc.d);
+        sc.h = nullptr; sc.d = nullptr; sc.cap = 0;
+        LPX_HIP_TRY(hipHostMalloc((void**)&sc.h, 2 * need));
+        LPX_HIP_TRY(hipMalloc((void**)&sc.d, 2 * need));
+        sc.cap = 2 * need;
+    }
+    for (int i = 0; i < count; ++i) {           // the finished runs used the group's stream; the nodes' own streams are idle, make sure
+        bool seen = false; for (int j = 0; j < i; ++j) if (ts[j]->stream == ts[i]->stream) { seen = true; break; }
+        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(ts[i]->stream));
+    }
+    ParkDesc* d = reinterpret_cast<ParkDesc*>(sc.h);
+    size_t maxd = 0;
     for (int i = 0; i < count; ++i) {
         lpx_store* s = ss[i]; lpx_tableau* t = ts[i];
         if (s->free_slots.empty()) {
@@ -1257,15 +1275,17 @@ int lpx_store_save_multi(lpx_store** ss, lpx_tableau** ts, int count, int* slots
             for (int k = s->per_chunk - 1; k >= 0; --k) s->free_slots.push_back(base + k);
         }
         const int slot = s->free_slots.back(); s->free_slots.pop_back();
-        LPX_HIP_TRY(hipMemcpyAsync(store_T(s, slot), t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, t->stream));
-        LPX_HIP_TRY(hipMemcpyAsync(store_b(s, slot), t->basis, sizeof(int32_t) * (t->R - 1), hipMemcpyDeviceToDevice, t->stream));
         s->R[slot] = t->R; s->C[slot] = t->C;
         slots[i] = slot;
+        d[i].srcT = t->T; d[i].dstT = store_T(s, slot); d[i].srcB = t->basis; d[i].dstB = store_b(s, slot);
+        d[i].doubles = (size_t)t->R * t->ld; d[i].m = t->R - 1; d[i].pad = 0;
+        maxd = std::max(maxd, d[i].doubles);
     }
-    for (int i = 0; i < count; ++i) {                                  // the handles may be reused, the slots read, right away
-        bool seen = false; for (int j = 0; j < i; ++j) if (ts[j]->stream == ts[i]->stream) { seen = true; break; }
-        if (!seen) LPX_HIP_TRY(hipStreamSynchronize(ts[i]->stream));
-    }
+    hipStream_t st = ts[0]->stream;
+    LPX_HIP_TRY(hipMemcpyAsync(sc.d, sc.h, need, hipMemcpyHostToDevice, st));
+    const int bpn = (int)std::min<size_t>(256, std::max<size_t>(1, maxd / 2 / 256 / 4));        // ~4 double2 per lane at least
+    LPX_HIP_TRY(launch_park_many(reinterpret_cast<const ParkDesc*>(sc.d), count, bpn, st));
+    LPX_HIP_TRY(hipStreamSynchronize(st));      // the handles may be reused, the slots read, right away
     return 0;
 }
 
