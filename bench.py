@@ -12,11 +12,13 @@ value (pivots/s)   The HBM-streaming workload: the dense random LP m=4096 n=8192
                    pristine HBM snapshot (D2D, inside the timed region) and runs the first `--pivots-per-step`
                    pivots of the solve from the slack basis -- default 10000, the reference's own iteration cap
                    (Models/PrimalSimplex.cs:54,95-96; the full solve needs 80477 pivots) -- on the streaming
-                   kernels lpx_select_mb + lpx_update_mb.  value = pivots of all ranks / max wall.
+                   kernel lpx_pivot_fused (one launch per pivot: update(k) out of place beside select(k+1)).
+                   value = pivots of all ranks / max wall.
                    A single LP does not shard (DESIGN.md "Multi-GPU"): with N ranks each rank solves its own
                    replica on its own GPU ("replicas only", weak scaling).
 Extra objects on the same JSON line (rank 0 unless stated):
-  roofline             lpx_update_mb (rank-1 pivot update, Models/PrimalSimplex.cs:251-256) in THAT solve:
+  roofline             lpx_pivot_fused (the rank-1 pivot update, Models/PrimalSimplex.cs:251-256, with the next
+                       pivot's selection riding in 32 of its 33 158 workgroups) in THAT solve:
                        16*R*C algorithmic bytes per launch / mean launch duration from HIP events bound to each
                        dispatch on the library's stream (hipExtLaunchKernelGGL start/stop events), measured live.
                        `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes over the same
@@ -60,26 +62,38 @@ def update_kernel(R, C):
     return "lpx::lpx_update_mb", ((units + 3) // 4) * 256
 
 
+def pivot_kernel(R, C):
+    """The kernel that streams the tableau in the PRIMAL loop: above 292 MiB lpx_pivot_fused -- update(k) out of place
+    (second tableau buffer) with select(k+1) in the first min(32, ceil(C/256)) workgroups of the same grid, 256-lane
+    workgroups of four update waves (run_fused, csrc/lpx_tableau.cpp; LPX_FUSED_PIVOT=0 restores the two-launch path) --
+    otherwise the update kernel above."""
+    ld = (C + 15) // 16 * 16
+    if 8 * ld * R > (292 << 20) and os.environ.get("LPX_FUSED_PIVOT", "1")[:1] != "0":
+        units = ((ld + 127) // 128) * ((R + 2) // 3)
+        return "lpx::lpx_pivot_fused", (min(32, (C + 255) // 256) + (units + 3) // 4) * 256
+    return update_kernel(R, C)
+
+
 def committed_profile(name):
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}")
     return (json.load(open(path)), os.path.relpath(path, ROOT)) if os.path.exists(path) else (None, None)
 
 
-def rocprof_kernel_us(R, C):
+def rocprof_kernel_us(R, C, primal=False):
     """Mean duration of the update kernel at this shape in the committed rocprofv3 --kernel-trace of this script
     (tools/trace_by_shape.py) -- a cross-check of the live HIP-event figure, NOT a measurement of this run."""
     d, _ = committed_profile("kernel_by_shape.json")
-    kernel, grid = update_kernel(R, C)
+    kernel, grid = pivot_kernel(R, C) if primal else update_kernel(R, C)
     e = d.get(f"{kernel}@grid{grid}x1") if d else None
     return e["mean_ns_live"] / 1e3 if e else None
 
 
-def pmc_traffic(R, C):
-    """HBM bytes per launch of lpx_update_mb from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+def pmc_traffic(R, C, primal=False):
+    """HBM bytes per launch of the tableau-streaming kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate runs, FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md; tools/pmc_summarise.py)."""
     d, src = committed_profile("pmc_traffic.json")
     if d:
-        kernel, grid = update_kernel(R, C)
+        kernel, grid = pivot_kernel(R, C) if primal else update_kernel(R, C)
         v = d.get(f"{kernel}@grid{grid}")
         if v:
             return v["hbm_bytes_per_launch"], src
@@ -218,8 +232,9 @@ def main():
             "batch": args.batch,
             "hipgraph": not args.no_graph,
             "device_loop_ms_per_step": loop_ms / max(args.steps, 1),
-            "path": "streaming (lpx_select_mb + lpx_update_mb per pivot)" if st["launches"] > 2
-                    else "resident (tableau in LDS, 1 launch per solve)",
+            "path": (("streaming, one launch per pivot (lpx_pivot_fused: update(k) out of place beside select(k+1))"
+                      if st["launches"] < 1.5 * max(st["pivots"], 1) else "streaming (lpx_select_mb + lpx_update_mb per pivot)")
+                     if st["launches"] > 2 else "resident (tableau in LDS, 1 launch per solve)"),
             "launches_per_step": st["launches"],
             "restore_inside_timed_region": True,
         },
@@ -342,7 +357,7 @@ def main():
         copy_gbs = 10 * 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
         torch.cuda.empty_cache()
-        # ---- roofline of the dominant kernel of THIS workload: lpx_update_mb in the real solve ------------
+        # ---- roofline of the dominant kernel of THIS workload: lpx_pivot_fused in the real solve ----------
         # profile = 1: eager launches, every update dispatch bracketed by its own HIP start/stop events on the
         # library's stream (hipExtLaunchKernelGGL); the same pivots as the timed solve (same LP, same start).
         alg = 16.0 * R * C
@@ -350,14 +365,14 @@ def main():
         status, pst = dt.primal_run(L.default_opts(False, batch=args.batch, profile=1, max_iter=args.roofline_pivots))
         k_ms = pst["update_ms_sum"] / max(pst["update_launches"], 1)
         ach = alg / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(R, C)
-        out["roofline"] = {"kernel": update_kernel(R, C)[0].split("::")[1], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+        traffic, traffic_src = pmc_traffic(R, C, primal=True)
+        out["roofline"] = {"kernel": pivot_kernel(R, C)[0].split("::")[1], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_src, "shape": [R, C],
                            "algorithmic_bytes_per_launch": alg, "avg_kernel_us": 1e3 * k_ms,
                            "launches": pst["update_launches"],
                            "timing": "HIP start/stop events bound to each dispatch on the library stream, this run",
-                           "rocprof_avg_kernel_us_committed": rocprof_kernel_us(R, C),
+                           "rocprof_avg_kernel_us_committed": rocprof_kernel_us(R, C, primal=True),
                            "measured_copy_gbs": copy_gbs, "frac_vs_measured_copy": ach / copy_gbs,
                            "whole_loop_us_per_pivot": 1e3 * loop_ms / max(pivots, 1)}
         # ---- north-star shape: raw 4096x8192 tableau (exactly 256 MiB = the Infinity Cache), forced pivots ----

@@ -65,6 +65,16 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
 hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int select_mb_blocks(int C);
+// Fused pivot (primal loop on tableaux beyond the Infinity Cache, lpx_pivot_fused in lpx_kernels.hip): ONE launch applies pivot k
+// out of place (buffer b -> buffer 1 - b) and, in its first `nblk` workgroups, selects pivot k + 1 from the tableau it reads.
+// P.T / P.prow / P.rhsbuf are the buffers of index 0, the members below those of index 1; P.col0 / P.col1 the factor columns.
+struct FusedParams {
+    SelParams P;
+    double* T1; double* prow1; double* rhs1;
+    DevState* rec;       // two state records; the one with the larger pad[2] (sequence number) is current, pad[3] = tableau buffer
+};
+hipError_t launch_fused_init(const FusedParams& f, hipStream_t s);
+hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);
 hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s,

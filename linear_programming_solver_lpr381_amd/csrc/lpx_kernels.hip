@@ -1046,6 +1046,260 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused pivot (primal loop, tableaux beyond the Infinity Cache): update(k) OUT OF PLACE + select(k+1), one launch.
+//
+// With the update in place, select(k+1) has to wait for update(k): it reads column q', row r' and the objective row of
+// T_{k+1}.  All three are rank-1 corrections of the same parts of T_k with data select(k) already produced (the factor
+// column and the normalised pivot row of pivot k) -- so if update(k) writes T_{k+1} into a SECOND buffer and leaves T_k
+// alone, select(k+1) depends on nothing update(k) produces and runs beside it: the first `nblk` workgroups of this grid are
+// lpx_select_mb's workgroups reading T_k through the correction `T_k[i,j] - fac_k[i] * prow_k[j]` (the very mul-then-sub
+// the update stores, so every value is bit-identical to what the two-launch path reads back from memory), the others are
+// the streaming update's waves.  A pivot then costs the sweep alone (117.7 us at 4097 x 12289 against 117.4 + 10.0);
+// tools/kbench/oop.hip measured the shape first: a ping-pong sweep is as fast as the in-place one (115.5 vs 116.0 us),
+// 256-lane workgroups cost it 1.6 us, and 32 select-shaped workgroups at the head of the grid another 0.5 us.
+//
+// Nothing is read and written inside one launch: everything a launch reads carries the index `c` of the CURRENT state
+// record (pivot row, factor column, RHS column) or is the source tableau; everything it writes carries 1 - c or is the
+// destination tableau.  Which record is current is decided on the device (larger sequence number, pad[2]), which buffer
+// holds T_k is part of the record (pad[3]) -- the launch arguments never change, so the loop captures into a graph as is.
+//   record c:  (r, q) = pivot k, selected but NOT yet applied ("pending"; r < 0: none)   qn = entering column of pivot k+1
+//   prow[c] = T_k[r,:] / T_k[r,q]     col[c] = T_k[:,q]     rhs[c] = T_k[:,C-1]
+// P.st is the host's copy of the current record, written by the first update workgroup: one launch behind.
+// A terminal status is found by select(k+1) in the launch that applies pivot k, so the tableau is complete when it shows.
+// ------------------------------------------------------------------------------------------------
+static constexpr int FP_NT = 256;
+
+// the ratios of pivot k+1's test, formed once per workgroup into its slice of P.ws: the scan then holds 16 ratios per lane
+// and nothing else (a scan over T_k's strided column with the correction applied on the fly needed 168 VGPRs, which
+// left the update waves of the same kernel 3 waves per SIMD and the sweep 10 us slower)
+struct CompactRatio {
+    const double* rat;
+    __device__ __forceinline__ double den(int i) const { return rat[i]; }
+    __device__ __forceinline__ double num(int) const { return 0.0; }
+    __device__ __forceinline__ double value(double a, double) const { return a; }
+};
+
+__global__ __launch_bounds__(SEL_NT) void lpx_fused_init(FusedParams F)
+{
+    __shared__ double s_v[SEL_NW];
+    __shared__ int s_i[SEL_NW];
+    const SelParams& P = F.P;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    ScanRule rule; rule.forced = 0; rule.eps = P.eps; rule.thresh = P.fthresh; rule.C = C; rule.c0 = 0;
+    // first entering column (ChooseEntering on the objective row as it stands) and the RHS column of record 0
+    int qn = -1;
+    if (P.st->status == LPX_RUNNING) qn = la_prepare_from_T(P, R, C, P.col0, R - 1, rule, s_v, s_i);
+    if (threadIdx.x == 0) {
+        DevState x = *P.st;
+        x.qn = qn; x.r = -1; x.q = -1; x.pad[2] = 1; x.pad[3] = 0;
+        F.rec[0] = x;
+        x.pad[2] = 0;
+        F.rec[1] = x;
+        P.part_i[MB_CNT] = 0;
+    }
+}
+
+// waves_per_eu(6): 78 VGPRs, no spills (86 without the hint = 5 waves per SIMD: 8.46 k pivots/s against 8.57 k; 64 VGPRs with 7 spills: 8.55 k)
+__global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_pivot_fused(FusedParams F, int ncw, int nunits, int mixmod)
+{
+    const SelParams& P = F.P;
+    const int t = threadIdx.x;
+    // both records in one round trip (every dependent load costs microseconds while the sweep saturates the memory system)
+    const DevState rec0 = F.rec[0], rec1 = F.rec[1];
+    const int c = (rec1.pad[2] > rec0.pad[2]) ? 1 : 0;
+    const DevState curv = c ? rec1 : rec0;
+    const DevState* cur = &curv;
+    DevState* nxt = F.rec + (c ^ 1);
+    const int status = cur->status;
+    const int pr = cur->r;                                   // pending pivot row (-1: nothing to apply)
+    const int seq = cur->pad[2], buf = cur->pad[3];
+    const int nsel = P.nblk;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    const size_t ld = (size_t)P.ld;
+    const double* __restrict__ src = buf ? F.T1 : P.T;
+    double* __restrict__ dst = buf ? P.T : F.T1;
+    const double* __restrict__ prowc = c ? F.prow1 : P.prow;
+    const double* __restrict__ facc = c ? P.col1 : P.col0;
+
+    if ((int)blockIdx.x >= nsel) {
+        // ---------------- update(k): T_{k+1} = T_k - fac (x) prow, row r replaced by the normalised pivot row ----------------
+        if ((int)blockIdx.x == nsel && t == 0) *P.st = *cur;
+        if (status != LPX_RUNNING || pr < 0) return;
+        const int lane = t & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int unit = ((int)blockIdx.x - nsel) * (FP_NT / 64) + wave;
+        if (unit >= nunits) return;
+        const int cw = unit % ncw, rb = unit / ncw;
+        const int col = cw * 128 + lane * 2;
+        if (col >= P.ld) return;
+        const int row0 = rb * UPDS_ROWS;
+        if (row0 >= R) return;
+        const double2 p = *reinterpret_cast<const double2*>(prowc + col);
+        const double* sb = src + (size_t)row0 * ld + col;
+        double* db = dst + (size_t)row0 * ld + col;
+        if (row0 + UPDS_ROWS <= R && (pr < row0 || pr >= row0 + UPDS_ROWS)) {
+            double2 v[UPDS_ROWS];
+            double f[UPDS_ROWS];
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) v[k] = upd_load<true>(sb + (size_t)k * ld);
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) f[k] = facc[row0 + k];
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) {
+                v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
+                v[k].y = v[k].y - f[k] * p.y;
+            }
+            // store policies as in lpx_update_mb_m / _s (two spelled-out sequences, checked in the ISA)
+            if (mixmod > 0 && (mixmod == 1 || rb % mixmod == 0)) {
+#pragma unroll
+                for (int k = 0; k < UPDS_ROWS - 1; ++k) upd_store<true>(db + (size_t)k * ld, v[k]);
+                upd_store<false>(db + (size_t)(UPDS_ROWS - 1) * ld, v[UPDS_ROWS - 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < UPDS_ROWS; ++k) upd_store<true>(db + (size_t)k * ld, v[k]);
+            }
+            return;
+        }
+#pragma unroll 1
+        for (int k = 0; k < UPDS_ROWS; ++k) {
+            const int i = row0 + k;
+            if (i >= R) break;
+            double2 o = p;                                   // row r: the normalised pivot row
+            if (i != pr) {
+                const double2 v = upd_load<true>(sb + (size_t)k * ld);
+                const double f = facc[i];
+                o.x = v.x - f * p.x;
+                o.y = v.y - f * p.y;
+            }
+            upd_store<true>(db + (size_t)k * ld, o);
+        }
+        return;
+    }
+
+    // ---------------- select(k+1) on T_{k+1}, read as T_k with pivot k's correction ----------------
+    const int b = blockIdx.x;
+    const int nbuf = pr >= 0 ? (buf ^ 1) : buf;              // where T_{k+1} lives once this launch is over
+    if (status != LPX_RUNNING) {
+        if (b == 0 && t == 0) { DevState x = *cur; x.pad[2] = seq + 1; *nxt = x; }
+        return;
+    }
+    double* __restrict__ prown = c ? P.prow : F.prow1;
+    double* __restrict__ facn = c ? P.col0 : P.col1;
+    const double* __restrict__ rhsc = c ? F.rhs1 : P.rhsbuf;
+    double* __restrict__ rhsn = c ? P.rhsbuf : F.rhs1;
+    const int m = R - 1;
+    const int iter = cur->iter, primal_count = cur->primal_count;
+    const int q = cur->qn;
+    int final_status = LPX_RUNNING, r = -1;
+    // loop head, Models/PrimalSimplex.cs:95-106
+    if (primal_count >= P.max_iter) final_status = LPX_ITER_LIMIT;
+    else if (q < 0) final_status = LPX_OPTIMAL;
+    double pq = 0.0, prhs = 0.0, fs = 0.0;
+    if (final_status == LPX_RUNNING) {
+        if (pr >= 0) { pq = prowc[q]; prhs = prowc[C - 1]; }
+        // T_{k+1}[i,q] and T_{k+1}[i,C-1] as the update stores them (mul, then sub; row r: the normalised pivot row)
+        auto den_of = [&](int i, double v, double f) { const double u = v - f * pq; return pr < 0 ? v : (i == pr ? pq : u); };
+        auto num_of = [&](int i, double h, double f) { const double u = h - f * prhs; return pr < 0 ? h : (i == pr ? prhs : u); };
+        double* rat = P.ws + (size_t)b * (size_t)(P.R > P.C ? P.R : P.C);
+        constexpr int U = 6;                                 // rows in flight per lane: three batches of loads at m = 4096
+        for (int i0 = 0; i0 < R; i0 += U * FP_NT) {
+            double v[U], f[U], h[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(R - 1, i0 + u * FP_NT + t);    // clamped, not guarded: a guarded load waits for its own branch
+                v[u] = src[(size_t)i * ld + q]; f[u] = facc[i]; h[u] = rhsc[i];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * FP_NT + t;
+                if (i < R) {
+                    const double dn = den_of(i, v[u], f[u]), nm = num_of(i, h[u], f[u]);
+                    rat[i] = dn > P.eps ? nm / dn : __builtin_inf();     // ChooseLeaving's ratio, :229-241
+                    if (b == 0) { facn[i] = dn; rhsn[i] = nm; }          // factors of pivot k+1, numerators of the test after it
+                    if (i == m) fs = dn;                                 // T_{k+1}[m,q]
+                }
+            }
+        }
+        // every lane needs fs: row m belongs to exactly one lane of the last batch
+        __shared__ double s_fs;
+        if (((m % (U * FP_NT)) % FP_NT) == t) s_fs = fs;
+        __syncthreads();                                     // the slice of ratios is complete (and visible: same CU)
+        fs = s_fs;
+        r = block_hysteresis_segments<FP_NT / 64>(m, P.tol_primal, CompactRatio{rat});
+        if (r < 0) final_status = LPX_UNBOUNDED;
+    }
+    if (final_status != LPX_RUNNING) {
+        if (b == 0 && t == 0) {
+            DevState x = *cur;
+            x.status = final_status; x.r = -1; x.q = -1; x.qn = -1; x.pad[2] = seq + 1; x.pad[3] = nbuf;
+            *nxt = x;
+        }
+        return;
+    }
+
+    ScanRule rule; rule.forced = 0; rule.eps = P.eps; rule.thresh = P.fthresh; rule.C = C; rule.c0 = 0;
+    const int per = (C + nsel - 1) / nsel;
+    const int j0 = b * per, j1 = min(C, j0 + per);
+    const double fr = facc[r], fm = facc[m];
+    const double* trow = src + (size_t)r * ld;
+    const double* orow = src + (size_t)m * ld;
+    const double pv = trow[q];
+    const double piv = pr < 0 ? pv : (r == pr ? pq : pv - fr * pq);      // T_{k+1}[r,q]
+    MinIdx best; rule_init(rule, best);
+#pragma unroll 2
+    for (int j = j0 + t; j < j1; j += FP_NT) {
+        const double pc = prowc[j], tv = trow[j], ov = orow[j];
+        const double tu = tv - fr * pc, ou = ov - fm * pc;
+        const double tr = pr < 0 ? tv : (r == pr ? pc : tu);     // T_{k+1}[r,j]
+        const double p = tr / piv;                               // true division, :250
+        prown[j] = p;
+        const double u = (pr < 0 ? ov : ou) - fs * p;            // what update(k+1) will store at T[m,j]
+        rule_feed(rule, best, j, u);
+    }
+    best = wave_min_idx(best);
+    // last-workgroup reduction of the partial argmins: the hand-off of lpx_select_mb (agent-scope stores, wait, barrier, one add)
+    if ((t & 63) == 0) {
+        const int slot = b * (FP_NT / 64) + (t >> 6);
+        __hip_atomic_store(&P.part_v[slot], best.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&P.part_i[slot], best.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < 64) {
+        int last = 0;
+        if (t == 0) last = (__hip_atomic_fetch_add(&P.part_i[MB_CNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsel - 1) ? 1 : 0;
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (last) {
+            MinIdx x; x.v = __builtin_inf(); x.i = INT_MAX;
+            const int npart = nsel * (FP_NT / 64);               // <= 128
+            if (t < npart) {
+                x.v = __hip_atomic_load(&P.part_v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x.i = __hip_atomic_load(&P.part_i[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (t + 64 < npart) {
+                MinIdx y;
+                y.v = __hip_atomic_load(&P.part_v[t + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                y.i = __hip_atomic_load(&P.part_i[t + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x = mi_pick(x, y);
+            }
+            x = wave_min_idx(x);
+            if (t == 0) {
+                nxt->qn = (x.i == INT_MAX) ? -1 : x.i;           // the one field of the record this workgroup writes
+                __hip_atomic_store(&P.part_i[MB_CNT], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (b == 0 && t == 0) {
+        P.basis[r] = q;                                          // basis[leaving] = entering, :110
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        nxt->status = LPX_RUNNING; nxt->iter = iter + 1; nxt->r = r; nxt->q = q;
+        nxt->phase = cur->phase; nxt->fdf_count = cur->fdf_count; nxt->dual_iter = cur->dual_iter;
+        nxt->primal_count = primal_count + 1; nxt->forced_k = cur->forced_k; nxt->c0n = 0; nxt->qn_valid = 0;
+        nxt->pad[0] = cur->pad[0]; nxt->pad[1] = cur->pad[1]; nxt->pad[2] = seq + 1; nxt->pad[3] = nbuf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #ifdef LPX_STAMPS
@@ -1252,6 +1506,25 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, e0, e1, 0, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nth), 0, s, T, ld, R, C, shape, prow, fac0, fac1, rhsbuf, st, ncw, nunits, mixmod);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_init(const FusedParams& f, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_fused_init, dim3(1), dim3(SEL_NT), 0, s, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int ld = f.P.ld, R = f.P.R;
+    const int ncw = (ld + 127) / 128, nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
+    const int nblocks = f.P.nblk + (nunits + (FP_NT / 64) - 1) / (FP_NT / 64);
+    const int mixmod = update_policy(ld, R) == 2 ? update_mixmod(ld, R) : 0;      // 0: every store nontemporal
+    if (e0 && e1)
+        hipExtLaunchKernelGGL(lpx_pivot_fused, dim3(nblocks), dim3(FP_NT), 0, s, e0, e1, 0, f, ncw, nunits, mixmod);
+    else
+        hipLaunchKernelGGL(lpx_pivot_fused, dim3(nblocks), dim3(FP_NT), 0, s, f, ncw, nunits, mixmod);
     return hipGetLastError();
 }
 

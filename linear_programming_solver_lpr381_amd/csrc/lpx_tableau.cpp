@@ -50,6 +50,10 @@ struct lpx_tableau {
     unsigned long long* xc = nullptr; unsigned long long* xq = nullptr;   // column-owning resident kernel: candidates / candidate columns
     size_t xc_bytes = 0, xq_bytes = 0;
     bool resident_off = false;      // a resident launch could not get its workgroups co-resident: stay on the streaming path
+    // fused pivot (lpx_pivot_fused): second tableau buffer and the index-1 copies of the small per-pivot vectors, on first use
+    double* fT = nullptr; char* fslab = nullptr;
+    double* fprow = nullptr; double* frhs = nullptr; DevState* frec = nullptr;
+    bool fused_off = false;         // the second buffer did not fit: stay on the two-launch path
 };
 
 static constexpr int LPX_RESIDENT_RETRY = -1000;     // internal: first resident launch timed out, state untouched
@@ -182,6 +186,7 @@ void lpx_tableau_destroy(lpx_tableau* t)
     for (hipEvent_t e : t->events) hipEventDestroy(e);
     hipFree(t->T); hipFree(t->slab); hipFree(t->snapT); hipFree(t->snapBasis);
     hipFree(t->frows); hipFree(t->fcols); hipFree(t->fchosen); hipFree(t->cutbuf);
+    hipFree(t->fT); hipFree(t->fslab);
     hipFree(t->xr); hipFree(t->xp); hipFree(t->xgen); hipFree(t->xbasis); hipFree(t->xT); hipFree(t->xc); hipFree(t->xq);
     if (t->hslab) hipHostFree(t->hslab);
     if (t->cutbuf_h) hipHostFree(t->cutbuf_h);
@@ -372,6 +377,55 @@ SelParams base_params(lpx_tableau* t, const lpx_run_opts* o, int mode)
         p.us = t->us; p.part_v = t->part_v; p.part_i = t->part_i; p.nblk = select_mb_blocks(t->Ccap); p.qsel = update_policy(t->ld, t->Rcap) != 0 ? 1 : 0;
     }
     return p;
+}
+
+// Fused pivot: buffers on first use.  Returns false (and remembers it) when the second tableau does not fit the device.
+static bool fused_buffers(lpx_tableau* t)
+{
+    if (t->fT) return true;
+    if (t->fused_off) return false;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t tb = sizeof(double) * (size_t)t->Rcap * t->ld;
+    const size_t sz[] = { up(sizeof(double) * t->ld), up(sizeof(double) * t->Rcap), up(2 * sizeof(DevState)) };
+    if (hipMalloc((void**)&t->fT, tb) != hipSuccess || hipMalloc((void**)&t->fslab, sz[0] + sz[1] + sz[2]) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(t->fT); hipFree(t->fslab);
+        t->fT = nullptr; t->fslab = nullptr; t->fused_off = true;
+        return false;
+    }
+    t->fprow = (double*)t->fslab;
+    t->frhs = (double*)(t->fslab + sz[0]);
+    t->frec = (DevState*)(t->fslab + sz[0] + sz[1]);
+    hipMemsetAsync(t->fT, 0, tb, t->stream);
+    hipMemsetAsync(t->fslab, 0, sz[0] + sz[1] + sz[2], t->stream);
+    return true;
+}
+
+// Primal loop with ONE launch per pivot (lpx_pivot_fused): update(k) out of place beside select(k+1).  The state record the
+// host polls is one launch behind the device's, so the loop gets a few iterations of slack; when it ends the tableau may sit
+// in the second buffer and is brought home (a device-to-device copy of the live rows, ~0.1 ms per 400 MB, once per solve).
+static int run_fused(lpx_tableau* t, const SelParams& p, const lpx_run_opts* o, lpx_stats* stats, int start_iter)
+{
+    FusedParams f; std::memset(&f, 0, sizeof(f));
+    f.P = p; f.T1 = t->fT; f.prow1 = t->fprow; f.rhs1 = t->frhs; f.rec = t->frec;
+    LoopCtx c; DevState init;
+    make_ctx(t, p, c, init);
+    c.key.assign(reinterpret_cast<const char*>(&f), sizeof(f));
+    c.enqueue_iter = [f](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { LPX_HIP_TRY(launch_pivot_fused(f, s, e0, e1)); return 0; };
+    // the prologue also selects the first pivot, so that every launch of the loop proper has a pivot to apply
+    c.prologue = [f](hipStream_t s) -> int { LPX_HIP_TRY(launch_fused_init(f, s)); LPX_HIP_TRY(launch_pivot_fused(f, s)); return 0; };
+    c.launches_per_iter = 1;
+    c.start_iter = start_iter;
+    const int rc = run_device_loop(c, init, o, (long long)o->max_iter + 4, nullptr, nullptr, stats);
+    LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    DevState recs[2];
+    LPX_HIP_TRY(hipMemcpy(recs, t->frec, sizeof(recs), hipMemcpyDeviceToHost));
+    const DevState& last = recs[1].pad[2] > recs[0].pad[2] ? recs[1] : recs[0];
+    if (last.pad[3] == 1) {
+        LPX_HIP_TRY(hipMemcpyAsync(t->T, t->fT, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, t->stream));
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    return rc;
 }
 
 // Exchange buffers of the resident kernels (sized for both of them) and the basis snapshot, allocated on first use.
@@ -830,6 +884,9 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
         if (o->resident > 0) { set_error("lpx_primal_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
     SelParams p = base_params(t, o, MODE_PRIMAL);
+    // streaming sizes without a per-pivot callback: one fused launch per pivot (LPX_FUSED_PIVOT=0: the two-launch path)
+    static const bool fused_env = [] { const char* e = std::getenv("LPX_FUSED_PIVOT"); return !(e && e[0] == '0'); }();
+    if (fused_env && p.us && p.qsel && !cb && fused_buffers(t)) return run_fused(t, p, o, st, resume);
     return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st, resume);
 }
 

@@ -13,6 +13,7 @@ Everything goes through the C ABI (ctypes).  The oracle is the checker only (ora
 the reference, which ships no fixtures)."""
 import hashlib
 import os
+import json
 import subprocess
 import sys
 import textwrap
@@ -73,23 +74,88 @@ def test_every_streaming_update_form_is_bitwise(oracle, env):
     assert got == [want, "True", str(count)], (env, got)
 
 
-def test_primal_solve_first_pivots_of_the_4096x8192_lp(gpu, oracle):
-    """The LP bench.py's headline value is measured on (m=4096, n=8192, tableau 4097x12289 = 403 MB, streaming
-    kernels lpx_select_mb + lpx_update_mb_m): first 150 pivots -- three hipGraph batches, so the hand-off of the entering
-    column from select's last workgroup to the update kernel crosses replays -- trace / basis / whole tableau bit-equal."""
+@pytest.mark.parametrize("cap", [150, 151])
+def test_primal_solve_first_pivots_of_the_4096x8192_lp(gpu, oracle, cap):
+    """The LP bench.py's headline value is measured on (m=4096, n=8192, tableau 4097x12289 = 403 MB, fused streaming
+    kernel lpx_pivot_fused: update(k) out of place beside select(k+1)): first 150 / 151 pivots -- three hipGraph batches;
+    an even and an odd count, so the tableau ends once in each of the two buffers -- trace / basis / whole tableau bit-equal."""
     c, A, b = synth.dense_lp(4096, 8192)
     T, basis = synth.primal_tableau_from(c, A, b)
     del A
     Tr, br = T.copy(), basis.copy()
-    st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=150)
+    st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=cap)
     with gpu.DeviceTableau.from_host(T, basis) as dt:
-        status, st = dt.primal_run(max_iter=150)
-        assert st["launches"] > 150                     # streaming path: two launches per pivot, not one resident launch
+        status, st = dt.primal_run(max_iter=cap)
+        assert st["launches"] > cap                     # streaming path: a launch per pivot, not one resident launch
+        assert st["pivots"] == cap
         tr = dt.trace()
         Tg, bg = dt.download()
-    assert status == st_ref == 3 and len(tr_ref) == 150
+    assert status == st_ref == 3 and len(tr_ref) == cap
     assert tr.tolist() == tr_ref.tolist() and bg.tolist() == br.tolist()
     assert np.array_equal(_bits(Tg), _bits(Tr))
+
+
+def _small_lps():
+    """(name, T, basis): LPs solved to the end -- optimal, unbounded, degenerate ties, and a second run on the same handle."""
+    out = []
+    for m, n, seed in [(48, 80, 3), (200, 320, 5), (130, 64, 7)]:
+        c, A, b = synth.dense_lp(m, n, seed=seed)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        out.append((f"dense{m}x{n}", T, basis))
+    c = np.array([1.0, 1.0]); A = np.array([[1.0, -1.0], [-1.0, 0.5]]); b = np.array([1.0, 2.0])
+    T, basis = synth.primal_tableau_from(c, A, b)
+    out.append(("unbounded", T, basis))
+    c = np.array([3.0, 2.0, 1.0]); A = np.array([[1.0, 1.0, 0.0], [1.0, 0.0, 1.0], [1.0, 1.0, 1.0], [2.0, 1.0, 0.0]])
+    b = np.array([4.0, 4.0, 4.0, 8.0])
+    T, basis = synth.primal_tableau_from(c, A, b)
+    out.append(("ties", T, basis))
+    return out
+
+
+@pytest.mark.parametrize("env", [{}, {"LPX_FUSED_PIVOT": "0"}, {"LPX_UPDATE_POLICY": "1"}], ids=["fused", "two-launch", "fused-all-nt"])
+def test_streaming_primal_loop_to_the_end_on_small_lps(oracle, env):
+    """The streaming primal loop run to its END -- optimal, unbounded, the iteration cap hit exactly at the optimum's pivot
+    count -- which the 403 MB LP is too long for: the streaming forms are forced onto small tableaux (LPX_UPDATE_POLICY,
+    resident kernels off; knobs read once per process, hence the child).  Fused (one launch per pivot, the default above the
+    Infinity Cache) and two-launch paths: status, pivot trace, basis and every bit of the tableau as the oracle's."""
+    want = []
+    for name, T, basis in _small_lps():
+        Tr, br = T.copy(), basis.copy()
+        st_ref, tr_ref = oracle.primal_tableau(Tr, br, max_iter=10000)
+        caps = [10000] + ([len(tr_ref), len(tr_ref) - 1] if len(tr_ref) > 1 else [])
+        for cap in caps:
+            Tc, bc = T.copy(), basis.copy()
+            s_c, t_c = oracle.primal_tableau(Tc, bc, max_iter=cap)
+            want.append([name, cap, int(s_c), len(t_c), hashlib.sha256(np.ascontiguousarray(t_c, dtype=np.int32).view(np.uint8)).hexdigest(),
+                         hashlib.sha256(np.ascontiguousarray(bc, dtype=np.int32).view(np.uint8)).hexdigest(),
+                         hashlib.sha256(np.ascontiguousarray(Tc).view(np.uint8)).hexdigest()])
+    code = textwrap.dedent("""
+        import hashlib, json, sys, numpy as np
+        sys.path.insert(0, %r)
+        import linear_programming_solver_lpr381_amd as L
+        from test_gpu_configs import _small_lps
+        h = lambda a, dt: hashlib.sha256(np.ascontiguousarray(a, dtype=dt).view(np.uint8)).hexdigest()
+        out = []
+        for name, T, basis in _small_lps():
+            caps = json.loads(sys.argv[1])[name]
+            with L.DeviceTableau.from_host(T, basis) as dt:
+                dt.snapshot()
+                for cap in caps:
+                    dt.restore()
+                    status, st = dt.primal_run(max_iter=cap, resident=-1)
+                    assert st["launches"] >= st["pivots"], st
+                    Tg, bg = dt.download()
+                    out.append([name, cap, int(status), int(st["pivots"]), h(dt.trace(), np.int32), h(bg, np.int32), h(Tg, np.float64)])
+        print(json.dumps(out))
+    """ % os.path.join(ROOT, "tests"))
+    caps = {}
+    for w in want:
+        caps.setdefault(w[0], []).append(w[1])
+    e = dict(os.environ, PYTHONPATH=ROOT, LPX_RESIDENT="0", **{"LPX_UPDATE_POLICY": "2", **env})
+    r = subprocess.run([sys.executable, "-c", code, json.dumps(caps)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got == want, [(g, w) for g, w in zip(got, want) if g != w]
 
 
 def test_config3_revised_vs_oracle_m1024(gpu, oracle):
