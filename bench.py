@@ -63,15 +63,17 @@ def update_kernel(R, C):
 
 
 def pivot_kernel(R, C):
-    """The kernel that streams the tableau in the PRIMAL loop: above 292 MiB lpx_pivot_fused -- update(k) out of place
-    (second tableau buffer) with select(k+1) in the first min(32, ceil(C/256)) workgroups of the same grid, 256-lane
-    workgroups of four update waves (run_fused, csrc/lpx_tableau.cpp; LPX_FUSED_PIVOT=0 restores the two-launch path) --
-    otherwise the update kernel above."""
+    """The kernel that streams the tableau in the PRIMAL loop (no per-pivot callback): lpx_pivot_fused -- update(k) out of
+    place (second tableau buffer) with select(k+1) in the first min(32, ceil(C/256)) workgroups of the same grid, 256-lane
+    workgroups of four update waves; `_c` (default cache policy) while both buffers share the Infinity Cache (<= 152 MiB
+    each), nontemporal loads + the mixed store policy above (run_fused / fused_policy, csrc).  LPX_FUSED_PIVOT=0 restores the
+    two-launch in-place path: then the update kernel above."""
     ld = (C + 15) // 16 * 16
-    if 8 * ld * R > (292 << 20) and os.environ.get("LPX_FUSED_PIVOT", "1")[:1] != "0":
-        units = ((ld + 127) // 128) * ((R + 2) // 3)
-        return "lpx::lpx_pivot_fused", (min(32, (C + 255) // 256) + (units + 3) // 4) * 256
-    return update_kernel(R, C)
+    if os.environ.get("LPX_FUSED_PIVOT", "1")[:1] == "0":
+        return update_kernel(R, C)
+    units = ((ld + 127) // 128) * ((R + 2) // 3)
+    name = "lpx::lpx_pivot_fused_c" if 8 * ld * R <= (152 << 20) else "lpx::lpx_pivot_fused"
+    return name, (min(32, (C + 255) // 256) + (units + 3) // 4) * 256
 
 
 def committed_profile(name):
@@ -420,9 +422,9 @@ def main():
                                        "pivots": rst["pivots"], "launches": rst["launches"],
                                        "pivots_per_s": rst["pivots"] / r_wall,
                                        "us_per_pivot": 1e6 * r_wall / max(rst["pivots"], 1)},
-                          "streaming": {"kernels": "lpx_select_mb + lpx_update_mb", "bound": "Infinity Cache (25 MB tableau)",
+                          "streaming": {"kernels": "lpx_pivot_fused_c (one launch per pivot, two 25 MB buffers)", "bound": "Infinity Cache (25 MB tableau)",
                                         "pivots_per_s": sst["pivots"] / (sst["loop_ms"] * 1e-3),
-                                        "update_avg_kernel_us": 1e3 * s2p["update_ms_sum"] / max(s2p["update_launches"], 1)}}
+                                        "kernel_avg_us": 1e3 * s2p["update_ms_sum"] / max(s2p["update_launches"], 1)}}
         d2.close()
         progress("revised leg (config 3)")
         # ---- config 3: revised simplex m=4096 n=8192 -----------------------------------------------------

@@ -73,6 +73,7 @@ struct FusedParams {
     double* T1; double* prow1; double* rhs1;
     DevState* rec;       // two state records; the one with the larger pad[2] (sequence number) is current, pad[3] = tableau buffer
 };
+int fused_policy(int ld, int R);             // 0 = default cache policy (lpx_pivot_fused_c), 2 = streaming mix, 1 = all nt
 hipError_t launch_fused_init(const FusedParams& f, hipStream_t s);
 hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);

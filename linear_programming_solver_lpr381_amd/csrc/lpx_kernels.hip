@@ -1100,7 +1100,10 @@ __global__ __launch_bounds__(SEL_NT) void lpx_fused_init(FusedParams F)
 }
 
 // waves_per_eu(6): 78 VGPRs, no spills (86 without the hint = 5 waves per SIMD: 8.46 k pivots/s against 8.57 k; 64 VGPRs with 7 spills: 8.55 k)
-__global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_pivot_fused(FusedParams F, int ncw, int nunits, int mixmod)
+// NT: nontemporal loads and (mixmod permitting) stores -- the streaming forms; false: default policy throughout, for a pair of
+// buffers that lives in the Infinity Cache together (lpx_pivot_fused_c)
+template <bool NT>
+__device__ __forceinline__ void lpx_pivot_fused_body(const FusedParams& F, int ncw, int nunits, int mixmod)
 {
     const SelParams& P = F.P;
     const int t = threadIdx.x;
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void
             double2 v[UPDS_ROWS];
             double f[UPDS_ROWS];
 #pragma unroll
-            for (int k = 0; k < UPDS_ROWS; ++k) v[k] = upd_load<true>(sb + (size_t)k * ld);
+            for (int k = 0; k < UPDS_ROWS; ++k) v[k] = upd_load<NT>(sb + (size_t)k * ld);
 #pragma unroll
             for (int k = 0; k < UPDS_ROWS; ++k) f[k] = facc[row0 + k];
 #pragma unroll
@@ -1150,13 +1153,13 @@ __global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void
                 v[k].y = v[k].y - f[k] * p.y;
             }
             // store policies as in lpx_update_mb_m / _s (two spelled-out sequences, checked in the ISA)
-            if (mixmod > 0 && (mixmod == 1 || rb % mixmod == 0)) {
+            if (NT && mixmod > 0 && (mixmod == 1 || rb % mixmod == 0)) {
 #pragma unroll
                 for (int k = 0; k < UPDS_ROWS - 1; ++k) upd_store<true>(db + (size_t)k * ld, v[k]);
                 upd_store<false>(db + (size_t)(UPDS_ROWS - 1) * ld, v[UPDS_ROWS - 1]);
             } else {
 #pragma unroll
-                for (int k = 0; k < UPDS_ROWS; ++k) upd_store<true>(db + (size_t)k * ld, v[k]);
+                for (int k = 0; k < UPDS_ROWS; ++k) upd_store<NT>(db + (size_t)k * ld, v[k]);
             }
             return;
         }
@@ -1166,12 +1169,12 @@ __global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void
             if (i >= R) break;
             double2 o = p;                                   // row r: the normalised pivot row
             if (i != pr) {
-                const double2 v = upd_load<true>(sb + (size_t)k * ld);
+                const double2 v = upd_load<NT>(sb + (size_t)k * ld);
                 const double f = facc[i];
                 o.x = v.x - f * p.x;
                 o.y = v.y - f * p.y;
             }
-            upd_store<true>(db + (size_t)k * ld, o);
+            upd_store<NT>(db + (size_t)k * ld, o);
         }
         return;
     }
@@ -1298,6 +1301,11 @@ __global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void
         nxt->pad[0] = cur->pad[0]; nxt->pad[1] = cur->pad[1]; nxt->pad[2] = seq + 1; nxt->pad[3] = nbuf;
     }
 }
+
+__global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_pivot_fused(FusedParams F, int ncw, int nunits, int mixmod)
+{ lpx_pivot_fused_body<true>(F, ncw, nunits, mixmod); }
+__global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_pivot_fused_c(FusedParams F, int ncw, int nunits, int mixmod)
+{ lpx_pivot_fused_body<false>(F, ncw, nunits, mixmod); }
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -1509,6 +1517,21 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
     return hipGetLastError();
 }
 
+// Cache policy of the fused launch.  Two buffers share the Infinity Cache, so the default policy only pays while BOTH fit with
+// room to spare; beyond that the streaming mix wins at every size, well below the in-place kernels' own crossover
+// (tools/probe_fused_mid.py, us per pivot, two-launch in place / fused default policy / fused streaming mix):
+//    57 MB 24.1 / 21.4 / 22.8     101 MB 37.8 / 30.5 / 34.3     157 MB 53.5 / 49.2 / 49.1     190 MB 64.5 / 65.5 / 58.3
+//   227 MB 73.1 / 77.2 / 69.0     266 MB 86.1 / 91.1 / 80.3     308 MB 102.7 / 92.4 / 92.2    403 MB 128.3 / 120.0 / 120.2
+static constexpr size_t FUSED_CACHED_BYTES = (size_t)152 << 20;
+int fused_policy(int ld, int R)
+{
+    static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_POLICY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    if (forced >= 0) return forced;
+    const size_t bytes = sizeof(double) * (size_t)ld * (size_t)R;
+    if (bytes <= FUSED_CACHED_BYTES) return 0;
+    return bytes <= UPD_MIXED_BYTES ? 2 : 1;
+}
+
 hipError_t launch_fused_init(const FusedParams& f, hipStream_t s)
 {
     hipLaunchKernelGGL(lpx_fused_init, dim3(1), dim3(SEL_NT), 0, s, f);
@@ -1520,11 +1543,13 @@ hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0
     const int ld = f.P.ld, R = f.P.R;
     const int ncw = (ld + 127) / 128, nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
     const int nblocks = f.P.nblk + (nunits + (FP_NT / 64) - 1) / (FP_NT / 64);
-    const int mixmod = update_policy(ld, R) == 2 ? update_mixmod(ld, R) : 0;      // 0: every store nontemporal
+    const int pol = fused_policy(ld, R);
+    const int mixmod = pol == 2 ? update_mixmod(ld, R) : 0;      // 0: every store nontemporal
+    auto kern = pol == 0 ? lpx_pivot_fused_c : lpx_pivot_fused;  // both buffers at home in the Infinity Cache: default policy
     if (e0 && e1)
-        hipExtLaunchKernelGGL(lpx_pivot_fused, dim3(nblocks), dim3(FP_NT), 0, s, e0, e1, 0, f, ncw, nunits, mixmod);
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(FP_NT), 0, s, e0, e1, 0, f, ncw, nunits, mixmod);
     else
-        hipLaunchKernelGGL(lpx_pivot_fused, dim3(nblocks), dim3(FP_NT), 0, s, f, ncw, nunits, mixmod);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FP_NT), 0, s, f, ncw, nunits, mixmod);
     return hipGetLastError();
 }
 

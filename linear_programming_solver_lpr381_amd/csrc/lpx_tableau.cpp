@@ -884,9 +884,9 @@ int lpx_primal_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void*
         if (o->resident > 0) { set_error("lpx_primal_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
     SelParams p = base_params(t, o, MODE_PRIMAL);
-    // streaming sizes without a per-pivot callback: one fused launch per pivot (LPX_FUSED_PIVOT=0: the two-launch path)
+    // without a per-pivot callback: one fused launch per pivot (LPX_FUSED_PIVOT=0: the two-launch in-place kernels)
     static const bool fused_env = [] { const char* e = std::getenv("LPX_FUSED_PIVOT"); return !(e && e[0] == '0'); }();
-    if (fused_env && p.us && p.qsel && !cb && fused_buffers(t)) return run_fused(t, p, o, st, resume);
+    if (fused_env && p.us && !cb && fused_buffers(t)) return run_fused(t, p, o, st, resume);
     return run_loop(t, p, o, (long long)o->max_iter + 2, cb, user, st, resume);
 }
 

@@ -112,12 +112,14 @@ def _small_lps():
     return out
 
 
-@pytest.mark.parametrize("env", [{}, {"LPX_FUSED_PIVOT": "0"}, {"LPX_UPDATE_POLICY": "1"}], ids=["fused", "two-launch", "fused-all-nt"])
+@pytest.mark.parametrize("env", [{}, {"LPX_FUSED_PIVOT": "0"}, {"LPX_UPDATE_POLICY": "1"}, {"LPX_UPDATE_POLICY": "0"}, {"LPX_UPDATE_POLICY": "0", "LPX_FUSED_PIVOT": "0"}],
+                         ids=["fused", "two-launch", "fused-all-nt", "fused-cached", "two-launch-cached"])
 def test_streaming_primal_loop_to_the_end_on_small_lps(oracle, env):
     """The streaming primal loop run to its END -- optimal, unbounded, the iteration cap hit exactly at the optimum's pivot
-    count -- which the 403 MB LP is too long for: the streaming forms are forced onto small tableaux (LPX_UPDATE_POLICY,
-    resident kernels off; knobs read once per process, hence the child).  Fused (one launch per pivot, the default above the
-    Infinity Cache) and two-launch paths: status, pivot trace, basis and every bit of the tableau as the oracle's."""
+    count -- which the 403 MB LP is too long for: every cache-policy form is forced onto small tableaux (LPX_UPDATE_POLICY,
+    resident kernels off; knobs read once per process, hence the child).  Fused (one launch per pivot: streaming mix, all
+    non-temporal, default policy) and two-launch in-place paths (LPX_FUSED_PIVOT=0: what runs under a per-pivot callback):
+    status, pivot trace, basis and every bit of the tableau as the oracle's."""
     want = []
     for name, T, basis in _small_lps():
         Tr, br = T.copy(), basis.copy()
