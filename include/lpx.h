@@ -62,7 +62,8 @@ typedef struct lpx_stats {
     double  loop_ms;         /* host wall time of the device-resident loop (no H2D/D2H) */
     double  h2d_ms;          /* upload time of one-shot entry points */
     double  d2h_ms;
-    double  update_ms_sum;   /* profile mode only: sum of HIP-event durations of the rank-1 update kernel */
+    double  update_ms_sum;   /* profile mode only: sum of HIP-event durations of the kernel that streams the tableau (the rank-1
+                              * update; the fused update + select launch of lpx_primal_run) */
     int64_t update_launches; /* profile mode only: launches included in update_ms_sum */
     int64_t fdf_pivots;      /* dual: pivots spent in ForceDualFeasibility */
     int64_t cleanup_pivots;  /* dual, repaired mode: pivots of the primal clean-up phase */
@@ -111,7 +112,10 @@ int  lpx_tableau_set_shape(lpx_tableau* t, int R, int C);
 
 /* The hot loops.  Each iteration is two launches on one stream:
  *   select  -- ChooseEntering + ChooseLeaving (+ pivot-row normalisation and pivot-column snapshot)
- *   update  -- the rank-1 Gauss-Jordan update T[i,:] -= T[i,q] * T[r,:]  (i != r)            */
+ *   update  -- the rank-1 Gauss-Jordan update T[i,:] -= T[i,q] * T[r,:]  (i != r)
+ * or, for lpx_primal_run without a per-pivot callback, ONE: the update written out of place into a second tableau buffer
+ * the library keeps beside the handle's own, with the next pivot's select in the same grid (the result is brought back
+ * into the handle's buffer before the call returns; LPX_FUSED_PIVOT=0 in the environment keeps the two-launch form).  */
 
 /* PrimalSimplex.Solve's while(true), Models/PrimalSimplex.cs:92-124
  * (ChooseEntering :205-220, ChooseLeaving :222-243, Pivot :245-257). */
