@@ -65,7 +65,7 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
 hipError_t launch_select_mb(const SelParams& p, hipStream_t s);
 hipError_t launch_update_mb(const SelParams& p, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 int select_mb_blocks(int C);
-// Fused pivot (primal loop on tableaux beyond the Infinity Cache, lpx_pivot_fused in lpx_kernels.hip): ONE launch applies pivot k
+// Fused pivot (primal loop without a per-pivot callback, lpx_pivot_fused / _c in lpx_kernels.hip): ONE launch applies pivot k
 // out of place (buffer b -> buffer 1 - b) and, in its first `nblk` workgroups, selects pivot k + 1 from the tableau it reads.
 // P.T / P.prow / P.rhsbuf are the buffers of index 0, the members below those of index 1; P.col0 / P.col1 the factor columns.
 struct FusedParams {

@@ -1046,7 +1046,7 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused pivot (primal loop, tableaux beyond the Infinity Cache): update(k) OUT OF PLACE + select(k+1), one launch.
+// Fused pivot (primal loop without a per-pivot callback, any size): update(k) OUT OF PLACE + select(k+1), one launch.
 //
 // With the update in place, select(k+1) has to wait for update(k): it reads column q', row r' and the objective row of
 // T_{k+1}.  All three are rank-1 corrections of the same parts of T_k with data select(k) already produced (the factor
@@ -1057,6 +1057,7 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
 // the streaming update's waves.  A pivot then costs the sweep alone (117.7 us at 4097 x 12289 against 117.4 + 10.0);
 // tools/kbench/oop.hip measured the shape first: a ping-pong sweep is as fast as the in-place one (115.5 vs 116.0 us),
 // 256-lane workgroups cost it 1.6 us, and 32 select-shaped workgroups at the head of the grid another 0.5 us.
+// Smaller tableaux gain more (tools/probe_fused_mid.py: 1.03-1.42x from 129 x 385 to 308 MB); cache policy: fused_policy below.
 //
 // Nothing is read and written inside one launch: everything a launch reads carries the index `c` of the CURRENT state
 // record (pivot row, factor column, RHS column) or is the source tableau; everything it writes carries 1 - c or is the
