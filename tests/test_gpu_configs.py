@@ -98,7 +98,8 @@ def test_primal_solve_first_pivots_of_the_4096x8192_lp(gpu, oracle, cap):
 def _small_lps():
     """(name, T, basis): LPs solved to the end -- optimal, unbounded, degenerate ties, and a second run on the same handle."""
     out = []
-    for m, n, seed in [(48, 80, 3), (200, 320, 5), (130, 64, 7)]:
+    # row counts around the fused select's batch (6 x 256 rows) and wave (64) boundaries, columns below one workgroup's slice
+    for m, n, seed in [(48, 80, 3), (200, 320, 5), (130, 64, 7), (255, 24, 11), (256, 24, 12), (1535, 20, 13), (1536, 20, 14), (1537, 20, 15)]:
         c, A, b = synth.dense_lp(m, n, seed=seed)
         T, basis = synth.primal_tableau_from(c, A, b)
         out.append((f"dense{m}x{n}", T, basis))
