@@ -255,6 +255,12 @@ def main():
             return [float(x.item()) for x in outl]
 
         def bnb_leg(problem, label, **kw):
+            if args.warmup > 0:
+                # untimed warm-up, as the headline's W steps: a short search with the same pool width, so that the handle
+                # pools, pinned staging and graph captures of this mode exist before the clock starts (a first search in
+                # a process measured 5.8 k warm nodes/s against 6.9-7.0 k for every later one, tools/probe_warm.py)
+                wkw = dict(kw, max_nodes=2 * kw.get("concurrent_nodes", 64))
+                L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **wkw).Solve(problem)
             solver = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw)
             barrier()
             t1 = time.perf_counter()
@@ -269,6 +275,7 @@ def main():
                     "pivots_per_node": piv_total / max(lp_total, 1), "wall_s": tb_max,
                     "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
                     "scaling": "strong (one global node budget, split over the ranks at the hand-out)",
+                    "warmup": "one untimed search of 2 x the pool width in nodes" if args.warmup > 0 else "none",
                     "per_rank_lp_relaxations": per_rank,
                     "imbalance_max_over_mean": max(per_rank) / max(sum(per_rank) / len(per_rank), 1e-9),
                     "levels": aux[0], "allreduces": aux[1], "rebalancing_rounds": aux[2], "node_descriptors_moved": aux[3],

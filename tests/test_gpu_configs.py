@@ -110,6 +110,10 @@ def _small_lps():
     b = np.array([4.0, 4.0, 4.0, 8.0])
     T, basis = synth.primal_tableau_from(c, A, b)
     out.append(("ties", T, basis))
+    T, basis = synth.primal_tableau_from(np.array([2.0]), np.array([[4.0]]), np.array([3.0]))      # one row, one column: 2 x 3
+    out.append(("one-by-one", T, basis))
+    T, basis = synth.primal_tableau_from(np.array([1.0, 3.0]), np.array([[1.0, 2.0], [3.0, 1.0]]), np.array([4.0, 6.0]))
+    out.append(("two-by-two", T, basis))
     return out
 
 
