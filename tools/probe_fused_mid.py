@@ -1,7 +1,7 @@
 """Diagnostic: the primal streaming loop on mid-size tableaux (between the LDS-resident limit and the Infinity Cache size),
 two-launch in place (LPX_FUSED_PIVOT=0) against the fused out-of-place launch, with the cache policy its launcher picks by
 size (default policy up to 152 MiB, lpx_pivot_fused_c) and with the streaming mix forced (LPX_UPDATE_POLICY=2).  Knobs are read once per process: one child per setting.
-Usage: python tools/probe_fused_mid.py [pivots]"""
+Usage: python tools/probe_fused_mid.py [pivots]     (PROBE_SIZES=8192x8192,... overrides the list of m x n)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r"""
@@ -9,7 +9,9 @@ import json, sys
 import linear_programming_solver_lpr381_amd as L
 from linear_programming_solver_lpr381_amd import synth
 out = {}
-for m, n in [(128, 256), (256, 512), (512, 1024), (1024, 2048), (1536, 3072), (2048, 4096), (2560, 5120), (2816, 5632), (3072, 6144), (3328, 6656), (3584, 7168), (4096, 8192)]:
+import os
+SIZES = [tuple(int(x) for x in s.split("x")) for s in os.environ["PROBE_SIZES"].split(",")] if os.environ.get("PROBE_SIZES") else None
+for m, n in SIZES or [(128, 256), (256, 512), (512, 1024), (1024, 2048), (1536, 3072), (2048, 4096), (2560, 5120), (2816, 5632), (3072, 6144), (3328, 6656), (3584, 7168), (4096, 8192)]:
     c, A, b = synth.dense_lp(m, n)
     T, basis = synth.primal_tableau_from(c, A, b)
     del A
