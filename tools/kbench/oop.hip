@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NTH) void upd(const double* __restrict__ src, doubl
                                           int r, int ncw, int nsel, int q, double* sink)
 {
     if ((int)blockIdx.x < nsel) {
-        if (NTH == 256) select_like256(src, ld, R, C, q, fac, prow, blockIdx.x, nsel, sink, reinterpret_cast<int*>(sink + 3000));
+        if (NTH >= 256) select_like256(src, ld, R, C, q, fac, prow, blockIdx.x, nsel, sink, reinterpret_cast<int*>(sink + 3000));
         else select_like(src, ld, R, C, q, fac, prow, blockIdx.x, nsel, sink);
         return;
     }
@@ -180,6 +180,12 @@ int main(int argc, char** argv)
     VAR256("ping-pong  shipped mix, 256-lane workgroups", true, 0);
     VAR256("ping-pong  shipped mix, 256-lane workgroups + 32 select-like (real chain)", true, 32);
     VAR256("ping-pong  shipped mix, 256-lane workgroups + 16 select-like (real chain)", true, 16);
+#define VARN(NAME, N) cv.push_back({NAME, [=](int it) { \
+        const double* a = (it & 1) ? T2 : T; double* b = (it & 1) ? T : T2; \
+        hipLaunchKernelGGL((upd<ROWS, 3, true, N>), dim3((total + N / 64 - 1) / (N / 64)), dim3(N), 0, s, a, b, ld, R, C, prow, fac, 7, ncw, 0, 1234, sink); }})
+    VARN("ping-pong  shipped mix, 128-lane workgroups", 128);
+    VARN("ping-pong  shipped mix, 192-lane workgroups", 192);
+    VARN("ping-pong  shipped mix, 512-lane workgroups", 512);
     VAR("in place   shipped mix again", 3, true, false, 0);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int pass = 0; pass < 2; ++pass)
