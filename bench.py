@@ -254,12 +254,16 @@ def main():
             dist.all_gather(outl, t)
             return [float(x.item()) for x in outl]
 
-        def bnb_leg(problem, label, **kw):
+        def bnb_leg(problem, label, warm_full=False, **kw):
             if args.warmup > 0:
                 # untimed warm-up, as the headline's W steps: a short search with the same pool width, so that the handle
                 # pools, pinned staging and graph captures of this mode exist before the clock starts (a first search in
-                # a process measured 5.8 k warm nodes/s against 6.9-7.0 k for every later one, tools/probe_warm.py)
-                wkw = dict(kw, max_nodes=2 * kw.get("concurrent_nodes", 64))
+                # a process measured 5.8 k warm nodes/s against 6.9-7.0 k for every later one, tools/probe_warm.py).
+                # warm_full: the SAME search once, untimed -- the warm-started mode parks parent tableaux in a store that
+                # grows by 1 GB hipMallocs, and the first process on a freshly booted box pays ~0.6 s for VRAM that has
+                # never been mapped (two of six bench runs: 4.5 k nodes/s instead of 6.8-7.2 k; the second process on the
+                # same box, even under rocprofv3, did not).
+                wkw = dict(kw) if warm_full else dict(kw, max_nodes=2 * kw.get("concurrent_nodes", 64))
                 L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **wkw).Solve(problem)
             solver = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw)
             barrier()
@@ -275,7 +279,8 @@ def main():
                     "pivots_per_node": piv_total / max(lp_total, 1), "wall_s": tb_max,
                     "incumbent": rb.OptimalValue if rb.OptimalValue > -1e300 else None,
                     "scaling": "strong (one global node budget, split over the ranks at the hand-out)",
-                    "warmup": "one untimed search of 2 x the pool width in nodes" if args.warmup > 0 else "none",
+                    "warmup": ("none" if args.warmup <= 0 else "the same search once, untimed" if warm_full
+                               else "one untimed search of 2 x the pool width in nodes"),
                     "per_rank_lp_relaxations": per_rank,
                     "imbalance_max_over_mean": max(per_rank) / max(sum(per_rank) / len(per_rank), 1e-9),
                     "levels": aux[0], "allreduces": aux[1], "rebalancing_rounds": aux[2], "node_descriptors_moved": aux[3],
@@ -297,7 +302,7 @@ def main():
         out["bnb_warm"] = bnb_leg(pb, "config 4, same sharded level search, children warm-started from the parent's final tableau (dual "
                                       f"loop only) -- an engine mode, not the reference's algorithm; GLOBAL budget {args.bnb_warm_nodes} nodes, "
                                       f"{args.bnb_warm_concurrent} node LPs per batch",
-                                  bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent, max_nodes=args.bnb_warm_nodes)
+                                  warm_full=True, bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent, max_nodes=args.bnb_warm_nodes)
         # what the node evaluation of config 4 amounts to in the path's unit (16*R*C bytes per pivot); the root
         # tableau's shape is a lower bound of every node's (a node at depth d has d more rows and columns)
         R0, C0 = 256 + 512 + 1, 512 + 256 + 512 + 1
