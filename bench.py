@@ -309,8 +309,9 @@ def main():
         for key, note in (("bnb", "the node tableaux live in LDS (lpx_resident_group, four nodes at a time): this is the rate a streaming "
                                   "implementation would have to sustain, not HBM traffic; the kernel is bound by its per-pivot exchange "
                                   "latency (9.4 us per pivot step of four nodes)"),
-                          ("bnb_warm", "batched streaming kernels lpx_select_b + lpx_update_b (HBM-bound; a batch runs as long as its "
-                                       "slowest node, on average 19 of 64 nodes are still active per step)")):
+                          ("bnb_warm", "batched streaming kernels lpx_select_b + lpx_update_b (HBM-bound: lpx_update_b moves the active nodes' "
+                                       "tableaux at ~6 TB/s), rolling batches of 64 node LPs refilled when half of them have finished "
+                                       "(lpx_multi_run_some); finished nodes of a batch still cost an early-exit workgroup each per step")):
             leg = out[key]
             rate = leg["pivots"] * 16.0 * R0 * C0 / leg["wall_s"] / 1e9
             leg["roofline"] = {"bound": "latency" if key == "bnb" else "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
