@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ.setdefault("LPX_FUSED_PIVOT", "0")     # the stamps live in lpx_select_la / lpx_select_mb: the two-launch path
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import linear_programming_solver_lpr381_amd as L
