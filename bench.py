@@ -181,6 +181,15 @@ def main():
         dist.all_reduce(b, op=dist.ReduceOp.MAX)
         return float(a.item()), float(b.item())
 
+    def gather_list(v):
+        """per-rank values (list over ranks)"""
+        if world == 1:
+            return [float(v)]
+        t = torch.tensor([float(v)], dtype=torch.float64, device=coll_dev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        return [float(x.item()) for x in outl]
+
     # ---- headline workload: primal tableau simplex on the m=4096 n=8192 LP (tableau 403 MB) -------
     m, n = args.m, args.n
     c, A, b = synth.dense_lp(m, n, seed=synth.SEED + rank)   # one replica per rank, own seed
@@ -195,6 +204,11 @@ def main():
         dt.restore()
         status, st = dt.primal_run(opts)
         assert status in (0, 3), f"solve ended with status {status}"     # OPTIMAL, or the iteration cap of the step
+        # a step that stopped at the cap has made exactly that many pivots; the default LP needs 80 477 (rank 0), so a
+        # shorter run there is a wrong run, not a fast one
+        assert status == 0 or st["pivots"] == args.pivots_per_step, f"cap reached after {st['pivots']} pivots"
+        assert not ((m, n) == (4096, 8192) and args.pivots_per_step <= 50000) or st["pivots"] == args.pivots_per_step, \
+            f"the headline LP stopped after {st['pivots']} pivots with status {status}"
         return st
 
     progress(f"headline solves ({R}x{C}, {args.pivots_per_step} pivots per step)")
@@ -211,6 +225,7 @@ def main():
     barrier()
     dt_s = time.perf_counter() - t0
     total_pivots, wall = reduce_sum_max(pivots, dt_s)
+    per_rank_pivots = gather_list(pivots)
 
     out = {
         "metric": METRIC,
@@ -231,6 +246,7 @@ def main():
                         "from the slack basis per step (the reference's iteration cap, Models/PrimalSimplex.cs:54)",
             "parallelism": "replicas only (one LP per GPU)" if world > 1 else "1 GPU",
             "pivots_per_step": pivots / max(args.steps, 1),
+            "per_rank_pivots": per_rank_pivots,
             "batch": args.batch,
             "hipgraph": not args.no_graph,
             "device_loop_ms_per_step": loop_ms / max(args.steps, 1),

@@ -71,11 +71,12 @@ int select_mb_blocks(int C);
 struct FusedParams {
     SelParams P;
     double* T1; double* prow1; double* rhs1;
-    DevState* rec;       // two state records; the one with the larger pad[2] (sequence number) is current, pad[3] = tableau buffer
+    DevState* rec;       // two state records: a launch reads rec[par] and writes rec[1 - par]; pad[2] = launch count, pad[3] = tableau buffer
+    int par;             // set per launch by launch_pivot_fused
 };
 int fused_policy(int ld, int R);             // 0 = default cache policy (lpx_pivot_fused_c), 2 = streaming mix, 1 = all nt
 hipError_t launch_fused_init(const FusedParams& f, hipStream_t s);
-hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+hipError_t launch_pivot_fused(const FusedParams& f, int par, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);
 hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s,

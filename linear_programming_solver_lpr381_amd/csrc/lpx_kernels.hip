@@ -1061,8 +1061,9 @@ hipError_t launch_build_node(const double* T0, int ld0, int R0, int C0, double* 
 //
 // Nothing is read and written inside one launch: everything a launch reads carries the index `c` of the CURRENT state
 // record (pivot row, factor column, RHS column) or is the source tableau; everything it writes carries 1 - c or is the
-// destination tableau.  Which record is current is decided on the device (larger sequence number, pad[2]), which buffer
-// holds T_k is part of the record (pad[3]) -- the launch arguments never change, so the loop captures into a graph as is.
+// destination tableau -- the state records included: a launch reads record `par` and writes record 1 - par, and `par` is a
+// launch argument that alternates (graph batches are even, so a replay starts where the capture did).  Which buffer holds
+// T_k is part of the record (pad[3]); pad[2] counts launches, for the host to find the last record written.
 //   record c:  (r, q) = pivot k, selected but NOT yet applied ("pending"; r < 0: none)   qn = entering column of pivot k+1
 //   prow[c] = T_k[r,:] / T_k[r,q]     col[c] = T_k[:,q]     rhs[c] = T_k[:,C-1]
 // P.st is the host's copy of the current record, written by the first update workgroup: one launch behind.
@@ -1108,10 +1109,12 @@ __device__ __forceinline__ void lpx_pivot_fused_body(const FusedParams& F, int n
 {
     const SelParams& P = F.P;
     const int t = threadIdx.x;
-    // both records in one round trip (every dependent load costs microseconds while the sweep saturates the memory system)
-    const DevState rec0 = F.rec[0], rec1 = F.rec[1];
-    const int c = (rec1.pad[2] > rec0.pad[2]) ? 1 : 0;
-    const DevState curv = c ? rec1 : rec0;
+    // Which record is current comes with the LAUNCH (F.par, alternating; run_fused), not from the records: the workgroups of a
+    // launch start over its whole duration, and one that started after workgroup 0 had written the next record must not
+    // take that for the current one.  (A first form compared sequence numbers on the device; it passed every test because
+    // select finishes late and the scalar cache kept serving the old line -- and broke when a second process shared the GPU.)
+    const int c = F.par & 1;
+    const DevState curv = F.rec[c];
     const DevState* cur = &curv;
     DevState* nxt = F.rec + (c ^ 1);
     const int status = cur->status;
@@ -1539,8 +1542,9 @@ hipError_t launch_fused_init(const FusedParams& f, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pivot_fused(const FusedParams& f, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+hipError_t launch_pivot_fused(const FusedParams& f0, int par, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
+    FusedParams f = f0; f.par = par & 1;
     const int ld = f.P.ld, R = f.P.R;
     const int ncw = (ld + 127) / 128, nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
     const int nblocks = f.P.nblk + (nunits + (FP_NT / 64) - 1) / (FP_NT / 64);

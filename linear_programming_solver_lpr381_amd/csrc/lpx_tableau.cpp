@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace lpx { const std::string& get_error(); extern int g_device; }
@@ -411,11 +412,20 @@ static int run_fused(lpx_tableau* t, const SelParams& p, const lpx_run_opts* o, 
     LoopCtx c; DevState init;
     make_ctx(t, p, c, init);
     c.key.assign(reinterpret_cast<const char*>(&f), sizeof(f));
-    c.enqueue_iter = [f](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int { LPX_HIP_TRY(launch_pivot_fused(f, s, e0, e1)); return 0; };
+    // A launch reads state record `par` and writes the other one; par alternates from launch to launch.  The prologue's launch is
+    // number 0, so the loop proper starts at 1 -- in the captured graph too (it is captured before the prologue runs, hence the
+    // counter is preset), and a graph batch is made even so that every replay starts at the parity the capture started at.
+    auto count = std::make_shared<long long>(1);
+    c.enqueue_iter = [f, count](hipStream_t s, hipEvent_t e0, hipEvent_t e1) -> int {
+        LPX_HIP_TRY(launch_pivot_fused(f, (int)(*count & 1), s, e0, e1)); ++*count; return 0; };
     // the prologue also selects the first pivot, so that every launch of the loop proper has a pivot to apply
-    c.prologue = [f](hipStream_t s) -> int { LPX_HIP_TRY(launch_fused_init(f, s)); LPX_HIP_TRY(launch_pivot_fused(f, s)); return 0; };
+    c.prologue = [f, count](hipStream_t s) -> int {
+        LPX_HIP_TRY(launch_fused_init(f, s)); LPX_HIP_TRY(launch_pivot_fused(f, 0, s)); *count = 1; return 0; };
     c.launches_per_iter = 1;
     c.start_iter = start_iter;
+    lpx_run_opts oe = *o;
+    { const int b = oe.batch > 0 ? oe.batch : 64; oe.batch = (b + 1) & ~1; }
+    o = &oe;
     const int rc = run_device_loop(c, init, o, (long long)o->max_iter + 4, nullptr, nullptr, stats);
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));
     DevState recs[2];
