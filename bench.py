@@ -276,9 +276,9 @@ def main():
                 # pools, pinned staging and graph captures of this mode exist before the clock starts (a first search in
                 # a process measured 5.8 k warm nodes/s against 6.9-7.0 k for every later one, tools/probe_warm.py).
                 # warm_full: the SAME search once, untimed -- the warm-started mode parks parent tableaux in a store that
-                # grows by 1 GB hipMallocs, and the first process on a freshly booted box pays ~0.6 s for VRAM that has
-                # never been mapped (two of six bench runs: 4.5 k nodes/s instead of 6.8-7.2 k; the second process on the
-                # same box, even under rocprofv3, did not).
+                # grows by 1 GB hipMallocs; they cost the leg up to half its time when the bench followed other GPU work on
+                # the box (4.5-4.8 k nodes/s instead of 6.8-7.2 k).  The library keeps a destroyed store's chunks for the
+                # next one, so after this warm-up the timed search allocates nothing.
                 wkw = dict(kw) if warm_full else dict(kw, max_nodes=2 * kw.get("concurrent_nodes", 64))
                 L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **wkw).Solve(problem)
             solver = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw)

@@ -166,7 +166,7 @@ int lpx_multi_solution(lpx_tableau** ts, int count, int nvars, double* x, double
  * the handles that use the store) and allocated 32 at a time. */
 typedef struct lpx_store lpx_store;
 int  lpx_store_create(int Rcap, int Ccap, lpx_store** out);
-void lpx_store_destroy(lpx_store* s);
+void lpx_store_destroy(lpx_store* s);   /* its device chunks stay with the process for the next store (up to LPX_STORE_CACHE_GB, default 64) */
 int  lpx_store_save(lpx_store* s, lpx_tableau* t, int* slot_out);
 int  lpx_store_release(lpx_store* s, int slot);
 /* The same for a batch of solved nodes (stores[i] / ts[i] / slots[i]): all copies are enqueued, then one wait per stream. */

@@ -4,7 +4,9 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace lpx { const std::string& get_error(); extern int g_device; }
@@ -1088,6 +1090,48 @@ int lpx_tableau_build_nodes(lpx_tableau** nodes, const lpx_tableau* root, int co
 }
 
 // ---- parent store: final tableaux of solved nodes parked in slab slots (warm-started B&B children) ----------
+// Chunks of a destroyed store are kept for the next one (per process, up to LPX_STORE_CACHE_GB, default 64): a warm-started
+// search parks thousands of parent tableaux and grows its store by 1 GB allocations, which cost a search that follows other
+// GPU work on the same box up to half its time (bench.py's warm B&B leg right after the GPU test suite: 4.5-4.8 k nodes/s
+// against 6.8-7.2 k; hipMalloc of memory another process has just released).
+namespace {
+std::mutex g_chunk_mu;
+std::multimap<size_t, void*> g_chunk_cache;
+size_t g_chunk_cached = 0;
+size_t chunk_cache_max()
+{
+    static const size_t v = [] { const char* e = std::getenv("LPX_STORE_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
+    return v;
+}
+hipError_t chunk_alloc(void** p, size_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_chunk_mu);
+        auto it = g_chunk_cache.find(bytes);
+        if (it != g_chunk_cache.end()) { *p = it->second; g_chunk_cache.erase(it); g_chunk_cached -= bytes; return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    // out of memory with chunks of other sizes in the cache: give them back and try once more
+    (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lk(g_chunk_mu);
+        for (auto& kv : g_chunk_cache) hipFree(kv.second);
+        g_chunk_cache.clear(); g_chunk_cached = 0;
+    }
+    return hipMalloc(p, bytes);
+}
+void chunk_release(void* p, size_t bytes)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_chunk_mu);
+        if (g_chunk_cached + bytes <= chunk_cache_max()) { g_chunk_cache.emplace(bytes, p); g_chunk_cached += bytes; return; }
+    }
+    hipFree(p);
+}
+}  // namespace
+
 struct lpx_store {
     int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 128;
     size_t slot_doubles = 0;                 // Rcap * ld
@@ -1110,8 +1154,8 @@ int lpx_store_create(int Rcap, int Ccap, lpx_store** out)
 void lpx_store_destroy(lpx_store* s)
 {
     if (!s) return;
-    for (double* p : s->chunks_T) hipFree(p);
-    for (int32_t* p : s->chunks_b) hipFree(p);
+    for (double* p : s->chunks_T) chunk_release(p, sizeof(double) * s->slot_doubles * s->per_chunk);
+    for (int32_t* p : s->chunks_b) chunk_release(p, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
     delete s;
 }
 
@@ -1124,8 +1168,8 @@ int lpx_store_save(lpx_store* s, lpx_tableau* t, int* slot_out)
     if (t->ld != s->ld || t->R > s->Rcap) { set_error("lpx_store_save: tableau does not match the store's capacity class"); return LPX_EINVAL; }
     if (s->free_slots.empty()) {
         double* Tc = nullptr; int32_t* bc = nullptr;
-        LPX_HIP_TRY(hipMalloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
-        hipError_t e = hipMalloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
+        LPX_HIP_TRY(chunk_alloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
+        hipError_t e = chunk_alloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
         if (e != hipSuccess) { hipFree(Tc); set_error("lpx_store_save: out of device memory"); return LPX_ENOMEM; }
         const int base = (int)s->chunks_T.size() * s->per_chunk;
         s->chunks_T.push_back(Tc); s->chunks_b.push_back(bc);
@@ -1333,8 +1377,8 @@ int lpx_store_save_multi(lpx_store** ss, lpx_tableau** ts, int count, int* slots
         lpx_store* s = ss[i]; lpx_tableau* t = ts[i];
         if (s->free_slots.empty()) {
             double* Tc = nullptr; int32_t* bc = nullptr;
-            LPX_HIP_TRY(hipMalloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
-            hipError_t e = hipMalloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
+            LPX_HIP_TRY(chunk_alloc((void**)&Tc, sizeof(double) * s->slot_doubles * s->per_chunk));
+            hipError_t e = chunk_alloc((void**)&bc, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
             if (e != hipSuccess) { hipFree(Tc); set_error("lpx_store_save_multi: out of device memory"); return LPX_ENOMEM; }
             const int base = (int)s->chunks_T.size() * s->per_chunk;
             s->chunks_T.push_back(Tc); s->chunks_b.push_back(bc);
