@@ -163,7 +163,7 @@ int lpx_tableau_solution2(lpx_tableau* t, int nvars, double* x, double* z, int32
 int lpx_multi_solution(lpx_tableau** ts, int count, int nvars, double* x, double* z, int32_t* basis_out, int basis_stride);
 /* Parent store: a solved node parks its final tableau in a slab slot (one D2D copy) and gives its handle
  * back; its children are assembled from the slot.  Slots are sized for one capacity class (same Rcap/Ccap as
- * the handles that use the store) and allocated 32 at a time. */
+ * the handles that use the store) and allocated 128 at a time. */
 typedef struct lpx_store lpx_store;
 int  lpx_store_create(int Rcap, int Ccap, lpx_store** out);
 void lpx_store_destroy(lpx_store* s);   /* its device chunks stay with the process for the next store (up to LPX_STORE_CACHE_GB, default 64) */
