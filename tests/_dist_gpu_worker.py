@@ -30,6 +30,23 @@ def main():
         return t.numpy()
 
     res = {"rank": rank}
+    # Both ranks stream the headline LP (403 MB tableau, fused launch) through the SHARED GPU at the same time: workgroups of a
+    # launch are then dispatched across context switches -- the situation in which a fused kernel that picked its state
+    # record by a device-side comparison ended a solve after 3 pivots.
+    import hashlib
+    c, A, b = synth.dense_lp(4096, 8192)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    del A
+    with L.DeviceTableau.from_host(T, basis) as dt:
+        dist.barrier()
+        status, st = dt.primal_run(max_iter=3000)
+        tr = dt.trace()
+        _, bg = dt.download()
+    res["primal"] = {"status": int(status), "pivots": int(st["pivots"]), "launches": int(st["launches"]),
+                     "trace150": np.asarray(tr[:150]).tolist(),
+                     "trace_sha": hashlib.sha256(np.ascontiguousarray(tr, dtype=np.int32).view(np.uint8)).hexdigest(),
+                     "basis_sha": hashlib.sha256(np.ascontiguousarray(bg, dtype=np.int32).view(np.uint8)).hexdigest()}
+    del T
     # a 0/1 IP small enough to be solved: cold level search with the depth-first-K pool, then the warm-started one
     cs, As, rels, bs = synth.binary_ip(24, 8, seed=11)
     ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)

@@ -1,5 +1,5 @@
-"""Sharded branch-and-bound and knapsack with the REAL device loops: two ranks share the visible GPU, the per-level exchange
-runs over gloo (the driver's multi-GPU runs use RCCL for the same callback).  Complements
+"""Sharded branch-and-bound and knapsack with the REAL device loops, and the streaming primal loop under GPU sharing: two ranks
+share the visible GPU, the per-level exchange runs over gloo (the driver's multi-GPU runs use RCCL for the same callback).  Complements
 tests/test_distributed_cpu.py, where the device loops are stood in for by the oracle."""
 import json
 import os
@@ -25,6 +25,17 @@ def test_two_ranks_on_one_gpu_agree_with_the_single_rank_search(gpu, oracle, tmp
         so, se = p.communicate(timeout=600)
         assert p.returncode == 0, se[-2000:]
     res = [json.load(open(o)) for o in outs]
+    # the streaming primal loop under GPU sharing: the full 3000 pivots on both ranks, the same ones, the oracle's first 150
+    c, A, b = synth.dense_lp(4096, 8192)
+    T, basis = synth.primal_tableau_from(c, A, b)
+    del A
+    st_ref, tr_ref = oracle.primal_tableau(T, basis, max_iter=150)
+    del T
+    for r in res:
+        assert r["primal"]["status"] == 3 and r["primal"]["pivots"] == 3000, r["primal"]
+        assert r["primal"]["launches"] < 1.1 * 3000 + 200                  # the fused path: one launch per pivot
+        assert r["primal"]["trace150"] == tr_ref.tolist()
+    assert res[0]["primal"]["trace_sha"] == res[1]["primal"]["trace_sha"] and res[0]["primal"]["basis_sha"] == res[1]["primal"]["basis_sha"]
     # single-rank references on the same problems
     cs, As, rels, bs = synth.binary_ip(24, 8, seed=11)
     ps = gpu.LPProblem.from_arrays(0, cs, As, rels, bs)
