@@ -204,10 +204,10 @@ def main():
         dt.restore()
         status, st = dt.primal_run(opts)
         assert status in (0, 3), f"solve ended with status {status}"     # OPTIMAL, or the iteration cap of the step
-        # a step that stopped at the cap has made exactly that many pivots; the default LP needs 80 477 (rank 0), so a
-        # shorter run there is a wrong run, not a fast one
+        # a step that stopped at the cap has made exactly that many pivots; the default LP of rank 0 needs 80 477, so a
+        # shorter run there is a wrong run, not a fast one (the other ranks' LPs -- other seeds -- are only held to the first rule)
         assert status == 0 or st["pivots"] == args.pivots_per_step, f"cap reached after {st['pivots']} pivots"
-        assert not ((m, n) == (4096, 8192) and args.pivots_per_step <= 50000) or st["pivots"] == args.pivots_per_step, \
+        assert not (rank == 0 and (m, n) == (4096, 8192) and args.pivots_per_step <= 50000) or st["pivots"] == args.pivots_per_step, \
             f"the headline LP stopped after {st['pivots']} pivots with status {status}"
         return st
 
