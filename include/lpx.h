@@ -92,6 +92,23 @@ int         lpx_init(int device);                /* binds this process to one GP
 int         lpx_last_error(char* buf, int len);  /* copies the last error message of this thread */
 int         lpx_device_name(char* buf, int len);
 
+/* ---- X1: the incumbent exchange between the processes of a sharded search (one process per GPU) ------------------
+ * Replaces, for a node queue sharded over the GPUs of one node, the compare-and-update of the single incumbent field the
+ * reference keeps (`BestObjective`, Models/Branch&Bound.cs:182,191; `_bestValue`, Models/BranchAndBoundKnapsack.cs:124,
+ * 157-160): ONE all-reduce(MAX) over FP64 per level / per round, RCCL over xGMI (ncclAllReduce, ncclMax, ncclDouble) on a
+ * communicator the library owns.  RCCL is bound at run time (dlopen of librccl.so.1; LPX_RCCL_LIB overrides the path), so
+ * single-GPU hosts need no RCCL.  Call after lpx_init(local GPU).  While a communicator exists, lpx_solve uses it for every
+ * sharded search whose lpx_solve_opts.allreduce_max is NULL (opts.rank / opts.world must then equal the communicator's). */
+#define LPX_COMM_ID_BYTES 128
+int lpx_comm_unique_id(uint8_t* id /* [LPX_COMM_ID_BYTES] */);   /* rank 0; the host ships the bytes to the other ranks */
+int lpx_comm_init(int rank, int world, const uint8_t* id);       /* collective over all ranks: ncclCommInitRank */
+/* The same for hosts without a side channel: rank 0 serves the id on host:port (TCP), the others fetch it there. */
+int lpx_comm_init_tcp(int rank, int world, const char* host, int port);
+int lpx_comm_allreduce_max(double* vals, int count);             /* MAX over ranks, in place (host buffer) */
+/* rank = -1 / world = 0 when no communicator exists; counters since lpx_comm_init.  Any pointer may be NULL. */
+int lpx_comm_info(int* rank, int* world, int64_t* allreduces, double* allreduce_ms, int* rccl_version);
+int lpx_comm_destroy(void);
+
 /* ---- device-resident tableau ---------------------------------------------------------------- */
 /* HBM layout: row-major with the leading dimension padded to a multiple of 16 doubles (128 B) so
  * that every row starts on a cache line and 16-byte vector accesses are aligned even for odd C. */

@@ -9,6 +9,7 @@
  *   node_lp      replaces lpx_multi_run + lpx_tableau_solution for ONE prepared node tableau
  *                (T is R x C row-major, modified in place; returns the LPX_* status)
  *   knap_relax   replaces lpx_knapsack_relax_batch (same argument meaning)
+ * A negative return value of node_lp is a device failure: the search throws, as it does when lpx_multi_run fails.
  */
 #ifndef LPX_TEST_H
 #define LPX_TEST_H
@@ -26,9 +27,17 @@ typedef struct lpx_test_seams {
                       const int8_t* fix_val, double* profit, double* weight, int32_t* frac_idx,
                       double* frac_val);
     void* user;
+    /* > 0: the branch-and-bound searches of this thread throw LPX_ENOMEM when a group of node LPs is about to be solved
+     * after this many nodes were handed out (real device loops or the stand-in above): the peer-failure path of the
+     * sharded searches -- every rank must come back with an error, none may wait in a collective for good. */
+    int64_t fail_after_nodes;
 } lpx_test_seams;
 
 void lpx_test_set_seams(const lpx_test_seams* seams);   /* NULL = none */
+
+/* The id hand-over of lpx_comm_init_tcp (include/lpx.h) without a device or RCCL behind it: rank 0 serves id[128] on
+ * host:port to the world - 1 other ranks, which receive it into id.  Returns 0 or LPX_EDEVICE (lpx_last_error). */
+int lpx_test_comm_exchange_id(int rank, int world, const char* host, int port, uint8_t* id);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@ Branch&Bound.cs, BranchAndBoundKnapsack.cs).  The compute path is liblpx.so (han
 behind the C ABI of include/lpx.h); this package is the host-side binding and has no CPU fallback.
 """
 from . import _lib
+from . import comm
 from ._lib import LpxError, default_opts
 from .tableau import DeviceTableau, primal_tableau, dual_tableau, multi_run
 from .revised import DeviceRevised, invert
@@ -12,7 +13,7 @@ from .solver import (BranchAndBound, BranchAndBoundKnapsack, BranchAndBoundRevis
                      LPSolver, ParseFromText, PrimalSimplex, Rel, RevisedPrimalSimplex, Sense, SimplexResult,
                      SolverException)
 
-__all__ = ["_lib", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau", "multi_run", "DeviceRevised", "invert", "LPSolver", "LPProblem", "Constraint", "Sense", "Rel",
+__all__ = ["_lib", "comm", "LpxError", "default_opts", "DeviceTableau", "primal_tableau", "dual_tableau", "multi_run", "DeviceRevised", "invert", "LPSolver", "LPProblem", "Constraint", "Sense", "Rel",
            "SimplexResult", "SolverException", "PrimalSimplex", "RevisedPrimalSimplex", "DualSimplex",
            "BranchAndBound", "BranchAndBoundKnapsack", "BranchAndBoundRevised", "ParseFromText", "DeviceKnapsack",
            "CuttingPlane", "CuttingPlaneRevised", "SensitivityAnalysis"]

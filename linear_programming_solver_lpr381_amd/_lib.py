@@ -67,7 +67,8 @@ class SolveOpts(C.Structure):
 
 class TestSeams(C.Structure):
     """include/lpx_test.h: test-only stand-ins for the device loops (never installed by the package itself)."""
-    _fields_ = [("node_lp", TEST_NODE_LP), ("knap_relax", TEST_KNAP_RELAX), ("user", C.c_void_p)]
+    _fields_ = [("node_lp", TEST_NODE_LP), ("knap_relax", TEST_KNAP_RELAX), ("user", C.c_void_p),
+                ("fail_after_nodes", C.c_int64)]
 
 
 class Result(C.Structure):
@@ -108,6 +109,13 @@ def lib() -> C.CDLL:
     L.lpx_init.argtypes = [C.c_int]
     L.lpx_last_error.argtypes = [C.c_char_p, C.c_int]
     L.lpx_device_name.argtypes = [C.c_char_p, C.c_int]
+    u8p = C.POINTER(C.c_uint8)
+    L.lpx_comm_unique_id.argtypes = [u8p]
+    L.lpx_comm_init.argtypes = [C.c_int, C.c_int, u8p]
+    L.lpx_comm_init_tcp.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.lpx_comm_allreduce_max.argtypes = [dp, C.c_int]
+    L.lpx_comm_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), dp, C.POINTER(C.c_int)]
+    L.lpx_comm_destroy.argtypes = []
     L.lpx_default_opts.argtypes = [C.POINTER(RunOpts), C.c_int]
     L.lpx_default_opts.restype = None
     L.lpx_tableau_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
@@ -179,6 +187,7 @@ def lib() -> C.CDLL:
     L.lpx_knapsack_relax_batch2.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_int8), dp, dp, ip, dp]
     L.lpx_test_set_seams.argtypes = [C.POINTER(TestSeams)]
     L.lpx_test_set_seams.restype = None
+    L.lpx_test_comm_exchange_id.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint8)]
     L.lpx_knapsack_expand_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int8), C.POINTER(C.c_int64),
                                             dp, dp, ip, dp]
     L.lpx_knapsack_expand_begin.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), ip, C.POINTER(C.c_int8), C.POINTER(C.c_int64)]

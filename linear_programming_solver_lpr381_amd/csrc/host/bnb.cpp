@@ -395,6 +395,8 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     lpx_run_opts po, dopt; lpx_default_opts(&po, 0); lpx_default_opts(&dopt, 1);
     po.max_iter = dopt.max_iter = c.opt.max_iter; po.batch = dopt.batch = c.opt.batch;
     if (c.opt.bnb_mode == 1) { dopt.fdf_guard = c.opt.max_iter; dopt.cleanup = 1; }
+    if (c.opt.test_fail_after_nodes > 0 && c.budget_used >= c.opt.test_fail_after_nodes && !group.empty())
+        throw LpxException(LPX_ENOMEM, "test seam: injected failure of a node group");       // include/lpx_test.h
     bool any_warm = false; for (NodeLP* lp : group) if (lp->warm) any_warm = true;
     bool rolling = false;
     if (any_warm) {                                               // dual feasible start: only the dual loop (and its clean-up) runs
@@ -418,7 +420,8 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             int st = c.opt.test_node_lp(lp->T.data(), lp->R, lp->C, lp->basis.data(), lp->dual ? 1 : 0, c.opt.bnb_mode,
                                         c.opt.max_iter, nvars, lp->x.data(), &lp->z, &piv);
             c.out->Stats.pivots += piv; lp->pivots = piv; lp->status = st;
-            if (st < 0 || st == LPX_ITER_LIMIT) lp->error = true;
+            if (st < 0) throw LpxException(st, "test seam: node LP failed");          // as collect_group does for lpx_multi_run
+            if (st == LPX_ITER_LIMIT) lp->error = true;
             else lp->has_solution = !(lp->dual && c.opt.bnb_mode == 0);
         }
         return;
@@ -654,7 +657,7 @@ void publish_best(Ctx& c, Exchange& ex, int nvars)
 void LevelSearch(Ctx& c)
 {
     const int world = std::max(1, c.opt.world), rank = c.opt.rank;
-    const bool sharded = world > 1 && (bool)c.opt.allreduce_max;
+    const bool sharded = (world > 1 || c.opt.shard_one) && (bool)c.opt.allreduce_max;
     Exchange ex{c, world, rank};
     c.tie_by_key = true;
     // The replicated warm-up only has to seed every rank with a subtree: 2 nodes per rank.  Its solves are
@@ -702,8 +705,9 @@ void LevelSearch(Ctx& c)
         try { solve_group(c, group, c.root->NumVars()); }
         catch (const LpxException& e) {
             // a rank that leaves the loop would leave its peers waiting in the level's all-reduce: keep taking part, tell them
-            if (!sharded || replicated) throw;
-            failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true;
+            // (also from the replicated warm-up: the peers meet this rank in their first all-reduce after the hand-out)
+            if (!sharded) throw;
+            failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true; replicated = false;
             for (size_t i = 0; i < frontier.size(); ++i) if (!skip[i]) skip[i] = 1;
         }
         std::vector<FNode> next;
@@ -733,7 +737,8 @@ void LevelSearch(Ctx& c)
         vals[1] = frontier.empty() ? 0.0 : 1.0;
         vals[2] = failed ? 1.0 : 0.0;
         vals[3] = (double)maxd;
-        vals[4 + rank] = c.stop ? -1.0 : (double)frontier.size();
+        // a rank whose share of the budget is used up takes no more nodes either: what it received would be dropped at the next level
+        vals[4 + rank] = (c.stop || c.over_budget()) ? -1.0 : (double)frontier.size();
         const double mine = vals[0];
         ex.max(vals.data(), (int)vals.size());
         if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
@@ -812,6 +817,8 @@ void WarmSearch(Ctx& c)
     c.count_work = !(replicated && rank != 0);
     c.budget_used = 0; c.budget_cap = c.opt.max_nodes; c.tie_by_key = true;
     Exchange ex{c, world, rank};
+    const bool sharded = (world > 1 || c.opt.shard_one) && (bool)c.opt.allreduce_max;
+    bool failed = false; std::string fail_msg; int fail_code = 0;
     const bool root_dual = has_ge_or_eq(*c.root);
     if (!ensure_template(c, root_dual)) return;
     const int w = root_dual ? 1 : 0;
@@ -835,12 +842,18 @@ void WarmSearch(Ctx& c)
         c.budget_used++;
         if (c.count_work) c.out->Nodes++;
         std::vector<NodeLP*> g{&lp};
-        solve_group(c, g, nvars);
-        int fl = 0, ce = 0;
-        const std::vector<Cut> none;
-        int k = decide(c, none, lp, 0, "Root Problem", fl, ce);
-        if (k < 0) { if (lp.kslot >= 0) lpx_store_release(lp.kstore, lp.kslot); return; }
-        add_children(frontier, none, 0, lp, k, fl, ce);
+        try {
+            solve_group(c, g, nvars);
+            int fl = 0, ce = 0;
+            const std::vector<Cut> none;
+            int k = decide(c, none, lp, 0, "Root Problem", fl, ce);
+            if (k < 0) { if (lp.kslot >= 0) lpx_store_release(lp.kstore, lp.kslot); return; }   // the same on every rank: nobody waits
+            add_children(frontier, none, 0, lp, k, fl, ce);
+        } catch (const LpxException& e) {
+            // the peers solve the same root and go on to their first level's all-reduce: meet them there (as LevelSearch does)
+            if (!sharded) throw;
+            failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true; replicated = false; frontier.clear();
+        }
     }
     for (;;) {
         if (replicated && frontier.size() >= want) {
@@ -868,7 +881,7 @@ void WarmSearch(Ctx& c)
         std::vector<NodeLP*> group;
         std::vector<char> skip(frontier.size(), 0);
         for (size_t i = 0; i < frontier.size(); ++i) {
-            if (c.over_budget()) { skip[i] = 1; c.stop = true; continue; }
+            if (failed || c.over_budget()) { skip[i] = 1; c.stop = true; continue; }
             c.budget_used++;
             if (c.count_work) c.out->Nodes++;
             if (frontier[i].depth > MaxDepth) { skip[i] = 2; continue; }
@@ -880,32 +893,44 @@ void WarmSearch(Ctx& c)
             lp.R = c.tplR[w] + frontier[i].depth; lp.C = c.tplC[w] + frontier[i].depth;
             group.push_back(&lp);
         }
-        solve_group(c, group, nvars);
-        for (const WNode& f : frontier) unref(f.store, f.slot);          // every child of this level is built
         std::vector<WNode> next;
-        for (size_t i = 0; i < frontier.size(); ++i) {
-            if (skip[i] == 1) continue;
-            if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
-            int fl = 0, ce = 0;
-            const double t0 = PhaseTimer::now();
-            int k = decide(c, frontier[i].cuts, lps[i], frontier[i].depth, "Node", fl, ce);
-            g_pt.decide += PhaseTimer::now() - t0;
-            if (k < 0) { if (lps[i].kslot >= 0) lpx_store_release(lps[i].kstore, lps[i].kslot); continue; }
-            add_children(next, frontier[i].cuts, frontier[i].depth, lps[i], k, fl, ce);
+        try {
+            solve_group(c, group, nvars);
+            for (const WNode& f : frontier) unref(f.store, f.slot);      // every child of this level is built
+            for (size_t i = 0; i < frontier.size(); ++i) {
+                if (skip[i] == 1) continue;
+                if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
+                int fl = 0, ce = 0;
+                const double t0 = PhaseTimer::now();
+                int k = decide(c, frontier[i].cuts, lps[i], frontier[i].depth, "Node", fl, ce);
+                g_pt.decide += PhaseTimer::now() - t0;
+                if (k < 0) { if (lps[i].kslot >= 0) lpx_store_release(lps[i].kstore, lps[i].kslot); continue; }
+                add_children(next, frontier[i].cuts, frontier[i].depth, lps[i], k, fl, ce);
+            }
+        } catch (const LpxException& e) {
+            // LPX_ENOMEM is the plausible one here (thousands of ~8 MB parent tableaux are parked).  A rank that left now would
+            // leave its peers waiting in this level's all-reduce: keep taking part with `failed` up, then stop together.  The
+            // parked tableaux go with the stores when the search's context is destroyed.
+            if (!sharded) throw;
+            failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true; replicated = false;
+            next.clear(); parked.clear();
         }
         frontier.swap(next);
         for (WNode& f : parked) frontier.push_back(std::move(f));
         c.levels++;
-        double vals[2] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0};
-        if (!replicated && world > 1 && c.opt.allreduce_max) {
+        // X1: incumbent, "someone still has work", "someone failed"
+        double vals[3] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0, failed ? 1.0 : 0.0};
+        if (!replicated && sharded) {
             const double mine = vals[0];
-            ex.max(vals, 2);
+            ex.max(vals, 3);
             if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
+            if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
         }
         if (vals[1] == 0.0) break;
     }
-    if (world > 1 && c.opt.allreduce_max && !replicated) publish_best(c, ex, nvars);
+    if (sharded && !replicated && !failed) publish_best(c, ex, nvars);
     c.out->Aux = {(double)c.levels, (double)c.allreduces, 0.0, 0.0};
+    if (failed) throw LpxException(fail_code ? fail_code : LPX_EDEVICE, fail_msg);
 }
 
 }  // namespace

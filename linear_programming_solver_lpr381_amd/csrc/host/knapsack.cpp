@@ -391,7 +391,9 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     const int world = std::max(1, opt.world), rank = opt.rank;
     const int64_t cap_nodes = opt.max_nodes;
     bool replicated = world > 1;
+    const bool sharded = (world > 1 || opt.shard_one) && (bool)opt.allreduce_max;
     const int round = 256;
+    bool failed = false; std::string fail_msg; int fail_code = 0;
     for (;;) {
         if (replicated && pq.d.size() >= (size_t)(4 * world)) {
             Heap mine;
@@ -403,23 +405,31 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
             if (rank != 0) { S.redundant_popped = S.popped; S.redundant_relax = S.relaxations; }   // rank 0 accounts for the warm-up
         }
         bool more = true;
-        for (int it = 0; it < round && more; ++it) {
-            if (cap_nodes > 0 && S.popped >= cap_nodes) { more = false; break; }
-            more = S.step(pq);
-            if (replicated && pq.d.size() >= (size_t)(4 * world)) break;
+        try {
+            for (int it = 0; it < round && more; ++it) {
+                if (cap_nodes > 0 && S.popped >= cap_nodes) { more = false; break; }
+                more = S.step(pq);
+                if (replicated && pq.d.size() >= (size_t)(4 * world)) break;
+            }
+        } catch (const LpxException& e) {
+            // a rank that left now would leave its peers waiting in the round's all-reduce: tell them, then stop together
+            if (!sharded) throw;
+            failed = true; fail_msg = e.what(); fail_code = e.code; more = false; replicated = false;
         }
-        if (world > 1 && !replicated && opt.allreduce_max) {
-            double vals[2] = {S.has_best ? S.best : -INFINITY, (more && !pq.d.empty()) ? 1.0 : 0.0};
+        if (sharded && !replicated) {
+            double vals[3] = {S.has_best ? S.best : -INFINITY, (more && !pq.d.empty()) ? 1.0 : 0.0, failed ? 1.0 : 0.0};
             const double mine = vals[0];
-            opt.allreduce_max(vals, 2);                                     // X1: incumbent + termination
+            opt.allreduce_max(vals, 3);                                     // X1: incumbent + termination (+ "someone failed")
             if (vals[0] > mine) { S.best = vals[0]; S.has_best = true; std::fill(S.bestX.begin(), S.bestX.end(), -1); }
+            if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
             if (vals[1] == 0.0) break;
         } else if (!more || pq.d.empty()) {
             if (cap_nodes > 0 && S.popped >= cap_nodes) break;
             if (pq.d.empty()) break;
         }
     }
-    if (world > 1 && opt.allreduce_max) {
+    if (failed) { try { S.finish_jobs(); } catch (const LpxException&) {} throw LpxException(fail_code ? fail_code : LPX_EDEVICE, fail_msg); }
+    if (sharded) {
         double own = (S.has_best && !S.bestX.empty() && S.bestX[0] >= 0) ? -(double)rank : -INFINITY;
         opt.allreduce_max(&own, 1);
         std::vector<double> xs(n, -INFINITY);

@@ -82,11 +82,13 @@ struct EngineOptions {
     // incumbent exchange: called once per level with {best_z, have_work}; must return the MAX over
     // ranks in place (RCCL all-reduce in production, identity for one process).
     std::function<void(double* vals, int count)> allreduce_max;
+    bool shard_one = false;          // diagnostic (LPX_COMM_SHARD_ONE): run the sharded code path with world == 1
     int max_iter = 10000;
     int bnb_dive = 0;                // sharded searches: 1 = depth-first-K pool policy
     bool quiet = false;              // internal solves whose Report nobody reads (B&B nodes): skip the canonical-form text,
                                      // hundreds of thousands of formatted numbers for a config-4 model
-    // test seams (see include/lpx.h); never set by product code
+    // test seams (see include/lpx_test.h); never set by product code
+    int64_t test_fail_after_nodes = 0;
     std::function<int(double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
                       double* x, double* z, int64_t* pivots)> test_node_lp;
     std::function<int(int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,

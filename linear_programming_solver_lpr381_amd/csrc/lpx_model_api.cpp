@@ -10,6 +10,8 @@
 using namespace lpx;
 using namespace lpx::host;
 
+namespace lpx { bool comm_active(int* rank, int* world); }
+
 namespace {
 
 char* dup_str(const std::string& s) { char* p = (char*)std::malloc(s.size() + 1); std::memcpy(p, s.c_str(), s.size() + 1); return p; }
@@ -37,10 +39,10 @@ LPProblem to_problem(const lpx_problem* p)
 }  // namespace
 
 // test-only stand-ins for the device loops (include/lpx_test.h); never set by a product path
-static thread_local lpx_test_seams g_seams = {nullptr, nullptr, nullptr};
+static thread_local lpx_test_seams g_seams = {nullptr, nullptr, nullptr, 0};
 extern "C" void lpx_test_set_seams(const lpx_test_seams* s)
 {
-    if (s) g_seams = *s; else g_seams = lpx_test_seams{nullptr, nullptr, nullptr};
+    if (s) g_seams = *s; else g_seams = lpx_test_seams{nullptr, nullptr, nullptr, 0};
 }
 
 static EngineOptions to_engine(const lpx_solve_opts* o)
@@ -55,12 +57,29 @@ static EngineOptions to_engine(const lpx_solve_opts* o)
     if (o->allreduce_max) {
         auto fn = o->allreduce_max; void* u = o->allreduce_user;
         e.allreduce_max = [fn, u](double* v, int n) { fn(u, v, n); };
+    } else {
+        // no host callback: the library's own RCCL communicator (lpx_comm_init) carries the exchange
+        int crank = 0, cworld = 0;
+        if (comm_active(&crank, &cworld)) {
+            if (e.world != cworld || e.rank != crank)
+                throw LpxException(LPX_EINVAL, "lpx_solve: opts.rank / opts.world (" + std::to_string(e.rank) + " / " + std::to_string(e.world) +
+                                               ") differ from the communicator's (" + std::to_string(crank) + " / " + std::to_string(cworld) + ")");
+            e.allreduce_max = [](double* v, int n) {
+                const int rc = lpx_comm_allreduce_max(v, n);
+                if (rc) { char b[512]; lpx_last_error(b, sizeof(b)); throw LpxException(rc, std::string("liblpx: ") + b); }
+            };
+            // LPX_COMM_SHARD_ONE=1 (diagnostic): a world of ONE still runs the sharded code path -- hand-out, one all-reduce per
+            // level / round through RCCL, publication of x -- so that path can be exercised on a single GPU
+            static const bool shard_one = [] { const char* v = std::getenv("LPX_COMM_SHARD_ONE"); return v && v[0] == '1'; }();
+            e.shard_one = shard_one && cworld == 1;
+        }
     }
     if (g_seams.node_lp) {
         auto fn = g_seams.node_lp; void* u = g_seams.user;
         e.test_node_lp = [fn, u](double* T, int R, int C, int32_t* basis, int dual, int repaired, int max_iter, int nvars,
                                  double* x, double* z, int64_t* pivots) { return fn(u, T, R, C, basis, dual, repaired, max_iter, nvars, x, z, pivots); };
     }
+    e.test_fail_after_nodes = g_seams.fail_after_nodes;
     if (g_seams.knap_relax) {
         auto fn = g_seams.knap_relax; void* u = g_seams.user;
         e.test_knap_relax = [fn, u](int count, const int32_t* off, const int32_t* fidx, const int8_t* fval, double* profit,

@@ -111,6 +111,8 @@ def _solve_opts(engine: dict):
     keep = []
     for k, v in engine.items():
         if k == "allreduce_max":
+            if v is None:
+                continue        # NULL: one process, or the library's own RCCL communicator (comm.py / lpx_comm_init)
             fn = v
 
             def _ar(_u, vals, count, fn=fn):
@@ -119,7 +121,7 @@ def _solve_opts(engine: dict):
             cb = _lib.ALLREDUCE_CB(_ar)
             keep.append(cb)
             o.allreduce_max = cb
-        elif k in ("test_node_lp", "test_knap_relax"):
+        elif k in ("test_node_lp", "test_knap_relax", "test_fail_after_nodes"):
             continue            # include/lpx_test.h seams: installed around the call by LPSolver.Solve
         elif hasattr(o, k):
             setattr(o, k, v)
@@ -180,8 +182,9 @@ class LPSolver:             # Models/LPSolver.cs:6-77
         ps, hold = _problem_struct(problem)
         r = _lib.Result()
         seams = None
-        if "test_node_lp" in self.engine or "test_knap_relax" in self.engine:      # test-only (include/lpx_test.h)
+        if "test_node_lp" in self.engine or "test_knap_relax" in self.engine or "test_fail_after_nodes" in self.engine:      # test-only (include/lpx_test.h)
             seams = _lib.TestSeams()
+            seams.fail_after_nodes = int(self.engine.get("test_fail_after_nodes", 0))
             if "test_node_lp" in self.engine:
                 seams.node_lp = _lib.TEST_NODE_LP(self.engine["test_node_lp"])
             if "test_knap_relax" in self.engine:

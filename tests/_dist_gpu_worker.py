@@ -47,6 +47,51 @@ def main():
                      "trace_sha": hashlib.sha256(np.ascontiguousarray(tr, dtype=np.int32).view(np.uint8)).hexdigest(),
                      "basis_sha": hashlib.sha256(np.ascontiguousarray(bg, dtype=np.int32).view(np.uint8)).hexdigest()}
     del T
+    sha = lambda a, dt=None: hashlib.sha256(np.ascontiguousarray(a, dtype=dt).view(np.uint8)).hexdigest()
+    # ---- the other launch types under the same sharing (workgroups of one launch dispatched across context switches): each
+    #      must give the bits a solo run gives.  Both ranks enter each section together (barrier) so the launches interleave.
+    # (a) revised loop at config-3 size: rv_price / rv_pick / rv_upd_ftran (lazy pending update of W) / rv_select2
+    c3, A3, b3 = synth.dense_lp(4096, 8192)
+    with L.DeviceRevised(A3, -c3, b3) as rv:
+        dist.barrier()
+        status, st = rv.run(max_iter=300, batch=50)
+        Bidx, Nidx, xB, z = rv.result()
+        tr = rv.trace()
+    res["revised"] = {"status": int(status), "pivots": int(st["pivots"]), "trace_sha": sha(tr, np.int32), "bidx_sha": sha(Bidx, np.int32),
+                      "nidx_sha": sha(Nidx, np.int32), "xb_sha": sha(xB, np.float64), "z_hex": float(z).hex()}
+    del A3
+    # (b) dual streaming pair lpx_select / lpx_update_s (`st` / `us` records) on a 361 MB tableau
+    m, n = 4500, 5500
+    cd, Ad, bd = synth.dense_lp(m, n, seed=11)
+    Td, basd = synth.primal_tableau_from(cd, Ad, bd)
+    del Ad
+    g = np.random.Generator(np.random.PCG64(11))
+    for i in g.choice(m, size=12, replace=False):
+        Td[i, :n] *= -1.0
+        Td[i, -1] = -0.02 * Td[i, -1]
+    with L.DeviceTableau.from_host(Td, basd) as dt:
+        dist.barrier()
+        status, st = dt.dual_run(fdf_guard=4, cleanup=1, max_iter=6)
+        tr = dt.trace()
+        Tg, bg = dt.download()
+    res["dual"] = {"status": int(status), "fdf": int(st["fdf_pivots"]), "trace": np.asarray(tr).tolist(), "basis_sha": sha(bg, np.int32),
+                   "T_sha": sha(Tg, np.float64)}
+    del Td, Tg
+    # (c) forced pivots on the two-launch kernels lpx_select_mb + lpx_update_mb_m at 4097 x 12289
+    T0 = synth.raw_tableau(4097, 12289)
+    rows, cols = synth.forced_pivot_list(4097, 12289, 8)
+    with L.DeviceTableau.from_host(T0) as dt:
+        dist.barrier()
+        chosen, st = dt.forced_pivots(rows, cols, 0.1)
+        Tg, _ = dt.download()
+    res["forced"] = {"chosen": np.asarray(chosen).tolist(), "pivots": int(st["pivots"]), "T_sha": sha(Tg, np.float64)}
+    del T0, Tg
+    # (d) one exact K7' (inv_select + lpx_update) at n = 600
+    gi = np.random.default_rng(6)
+    M = gi.uniform(-1, 1, size=(600, 600))
+    M[2, 0] = -M[1, 0]
+    dist.barrier()
+    res["invert"] = {"inv_sha": sha(L.invert(M), np.float64)}
     # a 0/1 IP small enough to be solved: cold level search with the depth-first-K pool, then the warm-started one
     cs, As, rels, bs = synth.binary_ip(24, 8, seed=11)
     ps = L.LPProblem.from_arrays(0, cs, As, rels, bs)
@@ -64,6 +109,15 @@ def main():
     calls["n"] = 0
     rk = L.BranchAndBoundKnapsack(max_nodes=0, concurrent_nodes=64, rank=rank, world=world, allreduce_max=allreduce_max).Solve(kp)
     res["knap"] = {"z": rk.OptimalValue, "x": rk.Extra.astype(int).tolist(), "popped": rk.Nodes, "allreduces": calls["n"]}
+    # a failing rank in the WARM-started search (thousands of parked parents make LPX_ENOMEM the plausible failure there): rank 1's
+    # 9th node group throws; both ranks must come back with an error after the same number of collectives
+    calls["n"] = 0
+    kw = {"test_fail_after_nodes": 9} if rank == 1 else {}
+    try:
+        L.BranchAndBound(bnb_mode=1, bnb_search=2, concurrent_nodes=4, rank=rank, world=world, allreduce_max=allreduce_max, **kw).Solve(ps)
+        res["warm_failure"] = {"error": None, "allreduces": calls["n"]}
+    except L.SolverException as e:
+        res["warm_failure"] = {"error": str(e), "code": e.code, "allreduces": calls["n"]}
     json.dump(res, open(out, "w"))
     dist.barrier()
     dist.destroy_process_group()

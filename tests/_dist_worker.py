@@ -122,6 +122,18 @@ def main():
     res["knap"] = {"z": kr.OptimalValue, "x": kr.Extra.astype(int).tolist(), "popped": kr.Nodes, "allreduces": calls["n"],
                    "feasible": bool((kr.Extra * w).sum() <= cap + 1e-9), "value": float((kr.Extra * pr).sum())}
     res["knap_ref"] = {"z": kref.best_z, "popped": kref.nodes_popped}
+    # --- a rank whose node group fails (LPX_ENOMEM through the test seam): BOTH ranks come back with an error, nobody waits in
+    #     a collective for good -- after the hand-out (rank 1 fails at its 6th node) and inside the replicated warm-up (2nd node)
+    res["peer_failure"] = []
+    for fail_at in (6, 2):
+        calls["n"] = 0
+        kw = {"test_fail_after_nodes": fail_at} if rank == 1 else {}
+        try:
+            L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, rank=rank, world=world,
+                             allreduce_max=allreduce_max, test_node_lp=node_lp, **kw).Solve(p)
+            res["peer_failure"].append({"error": None, "allreduces": calls["n"]})
+        except L.SolverException as e:
+            res["peer_failure"].append({"error": str(e), "code": e.code, "allreduces": calls["n"]})
     dist.barrier()
     dist.destroy_process_group()
     json.dump(res, open(out, "w"))

@@ -66,6 +66,58 @@ def test_world2_gloo_bnb_and_knapsack(tmp_path, lpx, oracle):
     assert r0["allreduces"] == r1["allreduces"]
     assert r0["aux"][2] >= 1 and r0["aux"][3] >= 1 and r0["aux"][2:] == r1["aux"][2:]      # same plan on both ranks
     assert min(r0["lp_solves"], r1["lp_solves"]) >= 0.25 * max(r0["lp_solves"], r1["lp_solves"])
+    # a failing rank: both ranks return an error (the failing one its own, the peer "a peer rank failed"), after the same
+    # number of collectives -- no rank is left waiting
+    for f0, f1 in zip(res[0]["peer_failure"], res[1]["peer_failure"]):
+        assert f0["error"] and "peer rank failed" in f0["error"], f0
+        assert f1["error"] and "injected failure" in f1["error"] and f1["code"] == -3, f1
+        assert f0["allreduces"] == f1["allreduces"] >= 1
+
+
+def test_comm_id_handover_over_tcp(lpx):
+    """lpx_comm_init_tcp's hand-over of the 128-byte RCCL id (rank 0 serves it, the others fetch it), without a device."""
+    import ctypes as C
+    import threading
+    L = lpx._lib.lib()
+    port = _free_port()
+    world = 4
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    got, rcs = [None] * world, [None] * world
+
+    def run(r):
+        buf = (C.c_uint8 * 128)(*(want if r == 0 else bytes(128)))
+        rcs[r] = L.lpx_test_comm_exchange_id(r, world, b"127.0.0.1", port, buf)
+        got[r] = bytes(buf)
+    ts = [threading.Thread(target=run, args=(r,)) for r in (2, 3, 1, 0)]     # rank 0 starts LAST: the others retry until it listens
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert rcs == [0] * world, (rcs, lpx._lib.last_error())
+    assert got == [want] * world
+
+
+def test_bench_launcher_starts_the_ranks_and_propagates_failure(tmp_path):
+    """`python bench.py --gpus N` without a launcher around it starts N ranks itself (before any GPU call); a mismatch between
+    --gpus and WORLD_SIZE is refused, so a 1-GPU number cannot pass for an N-GPU one."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(d["rank"] for d in lines) == [0, 1, 2] and all(d["world"] == 3 and d["local_rank"] == d["rank"] for d in lines)
+    assert len({d["master_port"] for d in lines}) == 1 and all(d["master_addr"] == "127.0.0.1" for d in lines)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--launch-check"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+    # a rank that dies takes the job down with a non-zero exit code (here: every rank, there is no GPU under the CPU suite;
+    # on a GPU box the check is skipped -- tests/test_gpu_distributed.py runs the launcher for real there)
+    import linear_programming_solver_lpr381_amd as Lp
+    if Lp._lib.lib().lpx_device_count() == 0:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-extras", "--steps", "1", "--warmup", "0"],
+                           env=dict(env, LPX_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and "ranks failed" in r.stderr, r.stderr[-2000:]
 
 
 def test_single_process_level_search_with_seam_matches_oracle(lpx, oracle):
