@@ -73,6 +73,19 @@ namespace Linear_Programming_Solver.Native
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_init(int device);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_last_error(byte[] buf, int len);
 
+        // ---- X1: the incumbent exchange of a sharded search, one process per GPU (include/lpx.h lpx_comm_*): the library owns an
+        //      RCCL communicator; BestObjective (Models/Branch&Bound.cs:182,191) / _bestValue (Models/BranchAndBoundKnapsack.cs:124)
+        //      become one ncclAllReduce(ncclMax, ncclDouble) per level / round.  lpx_init(localGpu) first.
+        public const int COMM_ID_BYTES = 128;
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_comm_unique_id(byte[] id);          // rank 0
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_comm_init(int rank, int world, byte[] id);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+        public static extern int lpx_comm_init_tcp(int rank, int world, [MarshalAs(UnmanagedType.LPUTF8Str)] string host, int port);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_comm_allreduce_max(double* vals, int count);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+        public static extern int lpx_comm_info(out int rank, out int world, out long allreduces, out double allreduceMs, out int rcclVersion);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int lpx_comm_destroy();
+
         // ---- loop-level entry points: the reference keeps its own model preparation and reports (INTEGRATION.md section 2) ----
         // replaces the while(true) of PrimalSimplex.Solve, Models/PrimalSimplex.cs:92-124
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]

@@ -77,6 +77,12 @@ struct FusedParams {
 int fused_policy(int ld, int R);             // 0 = default cache policy (lpx_pivot_fused_c), 2 = streaming mix, 1 = all nt
 hipError_t launch_fused_init(const FusedParams& f, hipStream_t s);
 hipError_t launch_pivot_fused(const FusedParams& f, int par, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// fused group step (lpx_group_fused / _c): one launch per step for a whole group of node LPs, see lpx_kernels.hip
+hipError_t launch_group_fused_init(const FusedParams* arr, const int* fresh, int nfresh, const DevState* init, hipStream_t s);
+hipError_t launch_group_fused_gather(const FusedParams* arr, int count, DevState* out, int* cur, hipStream_t s);
+int group_fused_blocks(int ld, int R);
+hipError_t launch_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, size_t live_bytes, hipStream_t s,
+                              hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);
 hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s,
@@ -164,6 +170,8 @@ struct LoopCtx {
     bool profile_maps = true;          // pivot k of a batch == k-th enqueued iteration
     int start_iter = 0;                // pivots already done on this tableau by another path (resident loop hand-over)
 };
+// graph executables parked for `owner` (the address of a handle's gexec slot): destroyed with the handle, or when its buffers change
+void graph_cache_drop_owner(const void* owner);
 int run_device_loop(LoopCtx& c, const DevState& init, const lpx_run_opts* o, long long budget,
                     lpx_pivot_cb cb, void* user, lpx_stats* stats);
 

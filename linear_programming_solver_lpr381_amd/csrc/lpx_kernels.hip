@@ -372,6 +372,7 @@ static constexpr size_t UPD_STREAM_BYTES = (size_t)292 << 20;   // 306 MB: measu
 // Hence: one row in three of every `mixmod`-th row block, mixmod = ceil(bytes / 768 MiB); all-nt beyond 8 GiB (unmeasured).
 static constexpr size_t UPD_MIXED_BYTES = (size_t)8192 << 20;
 static constexpr size_t UPD_MIX_STEP_BYTES = (size_t)768 << 20;
+static constexpr size_t FUSED_CACHED_BYTES = (size_t)152 << 20;   // fused (out-of-place) forms: both buffers at home in the Infinity Cache, see fused_policy
 
 typedef double lpx_d2 __attribute__((ext_vector_type(2)));
 // __builtin_nontemporal_load / _store lower to global_load_dwordx4 / global_store_dwordx4 ... nt on gfx950 and stay inside
@@ -393,6 +394,24 @@ template <bool STREAM> __device__ __forceinline__ void upd_store(double* p, doub
     } else {
         *reinterpret_cast<double2*>(p) = o;
     }
+}
+
+// The same through pointers KNOWN to be global memory.  A kernel that takes its buffers from a parameter record in memory (the
+// batched group kernels) sees generic pointers and would issue flat_load / flat_store, which count against both the vector-memory
+// and the LDS counter; casting to address space 1 gives global_load_dwordx4 / global_store_dwordx4 as in the single-tableau kernels.
+#define LPX_GLOBAL __attribute__((address_space(1)))
+template <bool STREAM> __device__ __forceinline__ double2 upd_load_g(const LPX_GLOBAL double* p)
+{
+    const LPX_GLOBAL lpx_d2* q = (const LPX_GLOBAL lpx_d2*)p;
+    lpx_d2 v;
+    if constexpr (STREAM) v = __builtin_nontemporal_load(q); else v = *q;
+    return make_double2(v.x, v.y);
+}
+template <bool STREAM> __device__ __forceinline__ void upd_store_g(LPX_GLOBAL double* p, double2 o)
+{
+    lpx_d2 v; v.x = o.x; v.y = o.y;
+    LPX_GLOBAL lpx_d2* q = (LPX_GLOBAL lpx_d2*)p;
+    if constexpr (STREAM) __builtin_nontemporal_store(v, q); else *q = v;
 }
 
 template <int ROWS = UPD_ROWS, int NTH = UPD_NT, int POLICY = 0>
@@ -1312,6 +1331,310 @@ __global__ __launch_bounds__(FP_NT) __attribute__((amdgpu_waves_per_eu(6))) void
 { lpx_pivot_fused_body<false>(F, ncw, nunits, mixmod); }
 
 // ------------------------------------------------------------------------------------------------
+// Fused GROUP step (K4g): the dual path's three-phase state machine (ForceDualFeasibility Models/DualSimplex.cs:195-228, dual
+// loop :36-113, repaired-mode primal clean-up; a primal node is "phase 2 from the start", Models/PrimalSimplex.cs:92-124) for a
+// whole group of node LPs in ONE launch per step: update(k) of every live node OUT OF PLACE beside select(k+1) of every live
+// node.  The dependency argument is K4f's: select(k+1) reads the RHS column, the objective row, one row and one column of
+// T_{k+1}, and each of them is a rank-1 correction of the same part of T_k by data select(k) left behind (factor column, normalised
+// pivot row) -- read as `T_k[i,j] - fac[i] * prow[j]`, the very mul-then-sub the update stores, so every value equals bit for bit
+// what the two-launch kernels (lpx_select_b + lpx_update_b) read back from memory.
+//
+// Grid (1-D): the first `nlive` workgroups are the selects, one per live node -- at the head of the grid so that their chain of
+// dependent loads runs beside the sweep instead of behind it -- then `per_node` update workgroups per live node (four waves of
+// 3 rows x 128 columns each, the streaming tile of lpx_pivot_fused).  `live` maps a slot of the grid to a node of `arr`: finished
+// nodes drop out of the grid between polls (the host rewrites the list), they do not cost early-exit workgroups.
+// No read-after-write inside a launch: a node's launch reads its record / pivot row / factor column / RHS column of index
+// c = (lpar ^ F.par) & 1 and its source tableau, and writes those of index 1 - c and the destination tableau; `lpar` is a launch
+// argument that alternates, F.par the node's own offset (set before the run by the host: a node joins a rolling batch at any
+// parity).  Scratch (P.ws) belongs to the node's select workgroup alone.
+// ------------------------------------------------------------------------------------------------
+static constexpr int FG_NT = 256;
+
+__global__ __launch_bounds__(FG_NT) void lpx_group_fused_init(const FusedParams* __restrict__ arr, const int* __restrict__ fresh,
+                                                              const DevState* __restrict__ init)
+{
+    // a node that starts (or continues from another path) in this run: both records from the host's initial state, the RHS
+    // column as it stands in the tableau; the node's current record is index F.par (launch 0 of the run has lpar = 0)
+    const int k = fresh[blockIdx.x];
+    const FusedParams F = arr[k];
+    const SelParams& P = F.P;
+    const int R = P.shape ? P.shape[0] : P.R, C = P.shape ? P.shape[1] : P.C;
+    const int c = F.par & 1;
+    double* rhsc = c ? F.rhs1 : P.rhsbuf;
+    for (int i = threadIdx.x; i < R; i += FG_NT) rhsc[i] = P.T[(size_t)i * P.ld + (C - 1)];
+    if (threadIdx.x == 0) {
+        DevState x = init[k];
+        x.r = -1; x.q = -1; x.qn = -1; x.pad[2] = 1; x.pad[3] = 0;
+        F.rec[c] = x;
+        x.pad[2] = 0;
+        F.rec[c ^ 1] = x;
+    }
+}
+
+// the latest record of every node (larger launch count) for the host and for the handle's own state record; which index it
+// was goes to `cur` (the node's F.par of its next run)
+__global__ __launch_bounds__(64) void lpx_group_fused_gather(const FusedParams* __restrict__ arr, DevState* __restrict__ out, int* __restrict__ cur)
+{
+    const FusedParams F = arr[blockIdx.x];
+    const int which = F.rec[1].pad[2] > F.rec[0].pad[2] ? 1 : 0;
+    const int32_t* s = reinterpret_cast<const int32_t*>(F.rec + which);
+    int32_t* d = reinterpret_cast<int32_t*>(out + blockIdx.x);
+    int32_t* d2 = reinterpret_cast<int32_t*>(F.P.st);
+    for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 64) { const int32_t v = s[k]; d[k] = v; d2[k] = v; }
+    if (threadIdx.x == 0) cur[blockIdx.x] = which;
+}
+
+template <bool NT>
+__device__ __forceinline__ void lpx_group_fused_body(const FusedParams* __restrict__ arr, const int* __restrict__ live, int nlive,
+                                                     int per_node, int lpar, int mixmod)
+{
+    __shared__ double s_v[FG_NT / 64];
+    __shared__ int s_i[FG_NT / 64];
+    const int t = threadIdx.x;
+    const int bid = blockIdx.x;
+    const bool is_select = bid < nlive;
+    const int slot = is_select ? bid : (bid - nlive) / per_node;
+    const int ublk = is_select ? 0 : (bid - nlive) % per_node;
+    const int node = __builtin_amdgcn_readfirstlane(live[slot]);      // workgroup-uniform: the record below stays in scalar registers
+    const FusedParams F = arr[node];
+    const SelParams& P = F.P;
+    const int c = (lpar ^ F.par) & 1;
+    // the record is workgroup-uniform but lives behind a pointer the kernel also writes through (index 1 - c), so the compiler
+    // loads it into VECTOR registers: every field that is used goes through readfirstlane, and nothing keeps the struct alive
+    const DevState* curp = F.rec + c;
+    DevState* nxt = F.rec + (c ^ 1);
+    const int status = __builtin_amdgcn_readfirstlane(curp->status);
+    const int pr = __builtin_amdgcn_readfirstlane(curp->r);          // pending pivot row (-1: nothing to apply)
+    const int seq = __builtin_amdgcn_readfirstlane(curp->pad[2]), buf = __builtin_amdgcn_readfirstlane(curp->pad[3]);
+    const int R = __builtin_amdgcn_readfirstlane(P.shape ? P.shape[0] : P.R), C = __builtin_amdgcn_readfirstlane(P.shape ? P.shape[1] : P.C);
+    const size_t ld = (size_t)P.ld;
+    const double* __restrict__ src = buf ? F.T1 : P.T;
+    double* __restrict__ dst = buf ? P.T : F.T1;
+    const double* __restrict__ prowc = c ? F.prow1 : P.prow;
+    const double* __restrict__ facc = c ? P.col1 : P.col0;
+
+    if (!is_select) {
+        // ---------------- update(k): T_{k+1} = T_k - fac (x) prow, row r replaced by the normalised pivot row ----------------
+        if (status != LPX_RUNNING || pr < 0) return;
+        const int ncw = (P.ld + 127) / 128;
+        const int nunits = ncw * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
+        const int lane = t & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int unit = ublk * (FG_NT / 64) + wave;
+        if (unit >= nunits) return;
+        const int cw = unit % ncw, rb = unit / ncw;
+        const int col = cw * 128 + lane * 2;
+        if (col >= P.ld) return;
+        const int row0 = rb * UPDS_ROWS;
+        const LPX_GLOBAL double* gprow = (const LPX_GLOBAL double*)prowc;
+        const LPX_GLOBAL double* gfac = (const LPX_GLOBAL double*)facc;
+        const double2 p = upd_load_g<false>(gprow + col);
+        const LPX_GLOBAL double* sb = (const LPX_GLOBAL double*)src + (size_t)row0 * ld + col;
+        LPX_GLOBAL double* db = (LPX_GLOBAL double*)dst + (size_t)row0 * ld + col;
+        if (row0 + UPDS_ROWS <= R && (pr < row0 || pr >= row0 + UPDS_ROWS)) {
+            double2 v[UPDS_ROWS];
+            double f[UPDS_ROWS];
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) v[k] = upd_load_g<NT>(sb + (size_t)k * ld);
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) f[k] = gfac[row0 + k];
+#pragma unroll
+            for (int k = 0; k < UPDS_ROWS; ++k) {
+                v[k].x = v[k].x - f[k] * p.x;       // mul, then sub: contraction is off
+                v[k].y = v[k].y - f[k] * p.y;
+            }
+            if (NT && mixmod > 0 && (mixmod == 1 || rb % mixmod == 0)) {
+#pragma unroll
+                for (int k = 0; k < UPDS_ROWS - 1; ++k) upd_store_g<true>(db + (size_t)k * ld, v[k]);
+                upd_store_g<false>(db + (size_t)(UPDS_ROWS - 1) * ld, v[UPDS_ROWS - 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < UPDS_ROWS; ++k) upd_store_g<NT>(db + (size_t)k * ld, v[k]);
+            }
+            return;
+        }
+#pragma unroll 1
+        for (int k = 0; k < UPDS_ROWS; ++k) {
+            const int i = row0 + k;
+            if (i >= R) break;
+            double2 o = p;                                   // row r: the normalised pivot row
+            if (i != pr) {
+                const double2 v = upd_load_g<NT>(sb + (size_t)k * ld);
+                const double f = gfac[i];
+                o.x = v.x - f * p.x;
+                o.y = v.y - f * p.y;
+            }
+            upd_store_g<NT>(db + (size_t)k * ld, o);
+        }
+        return;
+    }
+
+    // ---------------- select(k+1) on T_{k+1}, read as T_k with pivot k's correction ----------------
+    const int nbuf = pr >= 0 ? (buf ^ 1) : buf;              // where T_{k+1} lives once this launch is over
+    if (status != LPX_RUNNING) {
+        if (t == 0) { DevState x = *curp; x.pad[2] = seq + 1; *nxt = x; }
+        return;
+    }
+    double* __restrict__ prown = c ? P.prow : F.prow1;
+    double* __restrict__ facn = c ? P.col0 : P.col1;
+    const double* __restrict__ rhsc = c ? F.rhs1 : P.rhsbuf;
+    double* __restrict__ rhsn = c ? P.rhsbuf : F.rhs1;
+    const int m = R - 1, rhs = C - 1;
+    const size_t mx = (size_t)(P.R > P.C ? P.R : P.C);
+    double* zrow = P.ws;                                     // objective row of T_{k+1}
+    double* lrow = P.ws + mx;                                // row r of T_{k+1}
+    double* rat = P.ws + 2 * mx;                             // ratios of the scan at hand
+    const double inf = __builtin_inf();
+    {   // RHS column and objective row of T_{k+1}, as the update stores them (mul, then sub; row r: the normalised pivot row)
+        const double prhs = pr >= 0 ? prowc[rhs] : 0.0;
+        for (int i = t; i < R; i += FG_NT) {
+            const double h = rhsc[i];
+            double v = h;
+            if (pr >= 0) { const double u = h - facc[i] * prhs; v = (i == pr) ? prhs : u; }
+            rhsn[i] = v;
+        }
+        const double fm = pr >= 0 ? facc[m] : 0.0;
+        const double* orow = src + (size_t)m * ld;
+        for (int j = t; j < C; j += FG_NT) {
+            const double z = orow[j];
+            zrow[j] = pr >= 0 ? z - fm * prowc[j] : z;
+        }
+    }
+    __syncthreads();
+    // column q of T_{k+1} -> the factors of pivot k+1; with `ratios`: ChooseLeaving's ratios rhs_i / a_i (a_i > eps)
+    auto column = [&](int q, bool ratios) {
+        const double pq = pr >= 0 ? prowc[q] : 0.0;
+        for (int i = t; i < R; i += FG_NT) {
+            const double v = src[(size_t)i * ld + q];
+            double a = v;
+            if (pr >= 0) { const double u = v - facc[i] * pq; a = (i == pr) ? pq : u; }
+            facn[i] = a;
+            if (ratios && i < m) rat[i] = a > P.eps ? rhsn[i] / a : inf;
+        }
+    };
+    // row r of T_{k+1}; with `ratios`: the dual loop's ratios z_j / (-a_j) (a_j < -eps), Models/DualSimplex.cs:79-91
+    auto row = [&](int r, bool ratios) {
+        const double fr = pr >= 0 ? facc[r] : 0.0;
+        const double* trow = src + (size_t)r * ld;
+        for (int j = t; j < C; j += FG_NT) {
+            const double v = trow[j];
+            double a = v;
+            if (pr >= 0) { const double pc = prowc[j]; const double u = v - fr * pc; a = (r == pr) ? pc : u; }
+            lrow[j] = a;
+            if (ratios && j < rhs) rat[j] = a < -P.eps ? zrow[j] / (-a) : inf;
+        }
+    };
+    int phase = __builtin_amdgcn_readfirstlane(curp->phase);
+    const int fdf_count = __builtin_amdgcn_readfirstlane(curp->fdf_count), dual_iter = __builtin_amdgcn_readfirstlane(curp->dual_iter);
+    const int primal_count = __builtin_amdgcn_readfirstlane(curp->primal_count), iter = __builtin_amdgcn_readfirstlane(curp->iter);
+    int r = -1, q = -1;
+    int final_status = LPX_RUNNING;
+    bool have_row = false;
+    // ChooseEntering's column (first strict minimum of the objective row below -eps, Models/PrimalSimplex.cs:205-220) and the dual
+    // loop's leaving row (most negative RHS, Models/DualSimplex.cs:45-55) depend on T_{k+1} alone, not on the phase: both up front,
+    // so that the state machine below has ONE scan site (inlined once: its 16-ratio register block is what the kernel's
+    // register count -- shared with the update waves -- can afford)
+    const int qz = block_first_min_below<FG_NT>(zrow, 1, rhs, P.eps, s_v, s_i);
+    const int rr = block_first_min_below<FG_NT>(rhsn, 1, m, P.eps, s_v, s_i);
+    // state machine: ForceDualFeasibility -> dual loop -> (repaired mode) primal clean-up; the same hops as lpx_select_body
+    for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0; ++hop) {
+        int L; double tol;
+        if (phase == 0) {
+            if (fdf_count >= P.fdf_guard || qz < 0) { phase = 1; continue; }
+            q = qz; column(q, true); L = m; tol = P.tol_fdf;
+        } else if (phase == 1) {
+            if (dual_iter >= P.max_iter) { final_status = LPX_ITER_LIMIT; break; }
+            if (rr < 0) {
+                if (P.cleanup && qz >= 0) { phase = 2; continue; }
+                final_status = LPX_OPTIMAL; break;
+            }
+            row(rr, true); have_row = true; L = rhs; tol = P.tol_dual;
+        } else {
+            if (primal_count >= P.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
+            if (qz < 0) { final_status = LPX_OPTIMAL; break; }
+            q = qz; column(q, true); L = m; tol = P.tol_primal;
+        }
+        __syncthreads();                                     // the ratios are complete (and visible: same CU)
+        const int w = block_hysteresis_segments<FG_NT / 64>(L, tol, CompactRatio{rat});
+        __syncthreads();                                     // segment records and `rat` may be reused by the next scan
+        if (phase == 1) {
+            if (w < 0) { final_status = LPX_INFEASIBLE; break; }
+            r = rr; q = w;
+            column(q, false);
+        } else if (w < 0) {
+            q = -1;
+            if (phase == 0) { phase = 1; continue; }
+            final_status = LPX_UNBOUNDED; break;
+        } else r = w;
+    }
+    if (final_status != LPX_RUNNING || r < 0) {
+        if (t == 0) {
+            DevState x = *curp;
+            x.status = (final_status == LPX_RUNNING) ? LPX_OPTIMAL : final_status;
+            x.phase = phase; x.r = -1; x.q = -1; x.qn = -1; x.pad[2] = seq + 1; x.pad[3] = nbuf;
+            *nxt = x;
+        }
+        return;
+    }
+    // pivot prep (Models/PrimalSimplex.cs:249-250): the normalised pivot row of pivot k+1, true division
+    if (!have_row) row(r, false);
+    __syncthreads();
+    const double piv = lrow[q];
+    for (int j = t; j < C; j += FG_NT) prown[j] = lrow[j] / piv;
+    if (t == 0) {
+        P.basis[r] = q;                                          // basis[leaving] = entering, :110
+        if (iter < P.trace_cap) { P.trace[2 * iter] = r; P.trace[2 * iter + 1] = q; }
+        DevState x = *curp;
+        x.status = LPX_RUNNING; x.iter = iter + 1; x.r = r; x.q = q; x.phase = phase; x.qn = -1;
+        if (phase == 0) x.fdf_count = fdf_count + 1;
+        else if (phase == 1) x.dual_iter = dual_iter + 1;
+        else x.primal_count = primal_count + 1;
+        x.pad[2] = seq + 1; x.pad[3] = nbuf;
+        *nxt = x;
+    }
+}
+
+__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod)
+{ lpx_group_fused_body<true>(arr, live, nlive, per_node, lpar, mixmod); }
+__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused_c(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod)
+{ lpx_group_fused_body<false>(arr, live, nlive, per_node, lpar, mixmod); }
+
+hipError_t launch_group_fused_init(const FusedParams* arr, const int* fresh, int nfresh, const DevState* init, hipStream_t s)
+{
+    if (nfresh <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lpx_group_fused_init, dim3(nfresh), dim3(FG_NT), 0, s, arr, fresh, init);
+    return hipGetLastError();
+}
+hipError_t launch_group_fused_gather(const FusedParams* arr, int count, DevState* out, int* cur, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_group_fused_gather, dim3(count), dim3(64), 0, s, arr, out, cur);
+    return hipGetLastError();
+}
+// workgroups of the update part for a node of capacity (ld, R): four waves each
+int group_fused_blocks(int ld, int R)
+{
+    const int nunits = ((ld + 127) / 128) * ((R + UPDS_ROWS - 1) / UPDS_ROWS);
+    return (nunits + (FG_NT / 64) - 1) / (FG_NT / 64);
+}
+// live_bytes: tableau bytes of the live nodes (one buffer each): both buffers of the group at home in the Infinity Cache ->
+// default policy; beyond that nontemporal loads and the mixed store policy of lpx_pivot_fused
+hipError_t launch_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, size_t live_bytes, hipStream_t s,
+                              hipEvent_t e0, hipEvent_t e1)
+{
+    if (nlive <= 0) return hipSuccess;
+    static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_POLICY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    int pol = live_bytes <= FUSED_CACHED_BYTES ? 0 : (live_bytes <= UPD_MIXED_BYTES ? 2 : 1);
+    if (forced >= 0) pol = forced;
+    static const int mm_forced = [] { const char* e = std::getenv("LPX_UPDATE_MIXMOD"); return e ? std::atoi(e) : 0; }();
+    const int mixmod = pol == 2 ? (mm_forced > 0 ? mm_forced : (int)((live_bytes + UPD_MIX_STEP_BYTES - 1) / UPD_MIX_STEP_BYTES)) : 0;
+    auto kern = pol == 0 ? lpx_group_fused_c : lpx_group_fused;
+    const unsigned nblocks = (unsigned)nlive * (unsigned)(1 + per_node);
+    if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, e0, e1, 0, arr, live, nlive, per_node, lpar & 1, mixmod);
+    else hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, arr, live, nlive, per_node, lpar & 1, mixmod);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #ifdef LPX_STAMPS
@@ -1526,7 +1849,6 @@ hipError_t launch_update(double* T, int ld, int R, int C, const int32_t* shape, 
 // (tools/probe_fused_mid.py, us per pivot, two-launch in place / fused default policy / fused streaming mix):
 //    57 MB 24.1 / 21.4 / 22.8     101 MB 37.8 / 30.5 / 34.3     157 MB 53.5 / 49.2 / 49.1     190 MB 64.5 / 65.5 / 58.3
 //   227 MB 73.1 / 77.2 / 69.0     266 MB 86.1 / 91.1 / 80.3     308 MB 102.7 / 92.4 / 92.2    403 MB 128.3 / 120.0 / 120.2
-static constexpr size_t FUSED_CACHED_BYTES = (size_t)152 << 20;
 int fused_policy(int ld, int R)
 {
     static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_POLICY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();

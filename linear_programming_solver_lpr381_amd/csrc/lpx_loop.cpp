@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 
 namespace lpx {
@@ -57,15 +58,62 @@ double now_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-static void drop_graph(LoopCtx& c)
+// Graph executables are not destroyed because a run came with another parameter set (another iteration cap, another
+// forced-pivot list ...): the outgoing one is parked, keyed by its owner (the handle's gexec slot), batch and parameter bytes,
+// and taken back when the same parameters return -- alternating parameter sets (bench legs, B&B depth classes, the revised
+// path's drift-check segments) stop paying a capture + instantiate each time.  The park is bounded; the oldest entry is
+// destroyed when it overflows, and an owner's entries go with the owner (graph_cache_drop_owner).  LPX_GRAPH_KEEP=0 restores
+// destroy-at-once (diagnostic; it is NOT what the record r2_qt1 of DESIGN.md turned on: that abort shows with both settings).
+namespace {
+struct ParkedGraph { const void* owner; int batch; std::string key; hipGraphExec_t exec; };
+std::mutex g_park_mu;
+std::vector<ParkedGraph> g_park;                 // oldest first
+constexpr size_t kParkMax = 96;
+bool graph_keep()
 {
-    if (*c.gexec) { hipGraphExecDestroy(*c.gexec); *c.gexec = nullptr; *c.g_batch = 0; }
+    static const bool keep = [] { const char* e = std::getenv("LPX_GRAPH_KEEP"); return !(e && e[0] == '0'); }();
+    return keep;
+}
+}  // namespace
+
+void graph_cache_drop_owner(const void* owner)
+{
+    std::lock_guard<std::mutex> g(g_park_mu);
+    for (size_t i = 0; i < g_park.size();) {
+        if (g_park[i].owner == owner) { hipGraphExecDestroy(g_park[i].exec); g_park.erase(g_park.begin() + (long)i); }
+        else ++i;
+    }
+}
+
+static void retire_graph(LoopCtx& c)
+{
+    if (!*c.gexec) return;
+    if (!graph_keep()) { hipGraphExecDestroy(*c.gexec); *c.gexec = nullptr; *c.g_batch = 0; return; }
+    std::lock_guard<std::mutex> g(g_park_mu);
+    if (g_park.size() >= kParkMax) { hipGraphExecDestroy(g_park.front().exec); g_park.erase(g_park.begin()); }
+    g_park.push_back(ParkedGraph{(const void*)c.gexec, *c.g_batch, *c.g_key, *c.gexec});
+    *c.gexec = nullptr; *c.g_batch = 0;
+}
+
+static bool take_parked_graph(LoopCtx& c, int batch)
+{
+    std::lock_guard<std::mutex> g(g_park_mu);
+    for (size_t i = g_park.size(); i-- > 0;) {
+        ParkedGraph& e = g_park[i];
+        if (e.owner == (const void*)c.gexec && e.batch == batch && e.key == c.key) {
+            *c.gexec = e.exec; *c.g_batch = batch; *c.g_key = c.key;
+            g_park.erase(g_park.begin() + (long)i);
+            return true;
+        }
+    }
+    return false;
 }
 
 static int build_graph(LoopCtx& c, int batch)
 {
     if (*c.gexec && *c.g_batch == batch && *c.g_key == c.key) return 0;
-    drop_graph(c);
+    retire_graph(c);
+    if (take_parked_graph(c, batch)) return 0;
     hipGraph_t graph = nullptr;
     LPX_HIP_TRY(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
     for (int i = 0; i < batch; ++i) {

@@ -684,6 +684,7 @@ struct InvWork {
     ~InvWork() {
         if (stream) hipStreamSynchronize(stream);
         if (gexec) hipGraphExecDestroy(gexec);
+        graph_cache_drop_owner(&gexec);
         hipFree(A); hipFree(prow); hipFree(pcol); hipFree(st);
         if (hst) hipHostFree(hst);
     }
@@ -815,6 +816,7 @@ void lpx_revised_destroy(lpx_revised* r)
     if (!r) return;
     if (r->stream) hipStreamSynchronize(r->stream);
     if (r->gexec) hipGraphExecDestroy(r->gexec);
+    graph_cache_drop_owner(&r->gexec);
     for (hipEvent_t e : r->events) hipEventDestroy(e);
     if (r->ev0) hipEventDestroy(r->ev0);
     if (r->ev1) hipEventDestroy(r->ev1);

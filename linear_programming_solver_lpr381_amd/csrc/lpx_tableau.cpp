@@ -57,6 +57,8 @@ struct lpx_tableau {
     double* fT = nullptr; char* fslab = nullptr;
     double* fprow = nullptr; double* frhs = nullptr; DevState* frec = nullptr;
     bool fused_off = false;         // the second buffer did not fit: stay on the two-launch path
+    bool suspended2 = false;        // ... by the two-launch group kernels (it must continue there: no pending pivot, state in *hst)
+    bool fsuspended = false; int frec_cur = 0;   // fused group run left unfinished: its records (latest: index frec_cur) are in place
 };
 
 static constexpr int LPX_RESIDENT_RETRY = -1000;     // internal: first resident launch timed out, state untouched
@@ -64,6 +66,7 @@ static constexpr int LPX_RESIDENT_RETRY = -1000;     // internal: first resident
 static void drop_graph(lpx_tableau* t)
 {
     if (t->gexec) { hipGraphExecDestroy(t->gexec); t->gexec = nullptr; t->g_batch = 0; }
+    graph_cache_drop_owner(&t->gexec);          // the parked ones captured the same buffers
 }
 
 extern "C" {
@@ -208,7 +211,7 @@ int lpx_tableau_shape(const lpx_tableau* t, int* R, int* C, int* ld)
 int lpx_tableau_upload(lpx_tableau* t, const double* T, const int32_t* basis)
 {
     if (!t || !T) { set_error("lpx_tableau_upload: null argument"); return LPX_EINVAL; }
-    t->suspended = false;
+    t->suspended = t->suspended2 = t->fsuspended = false;
     LPX_HIP_TRY(hipMemcpy2DAsync(t->T, sizeof(double) * t->ld, T, sizeof(double) * t->C,
                                  sizeof(double) * t->C, t->R, hipMemcpyHostToDevice, t->stream));
     if (basis && t->R > 1)
@@ -248,6 +251,7 @@ int lpx_tableau_snapshot(lpx_tableau* t)
 int lpx_tableau_restore(lpx_tableau* t)
 {
     if (!t || !t->snapT) { set_error("lpx_tableau_restore: no snapshot"); return LPX_EINVAL; }
+    t->suspended = t->suspended2 = t->fsuspended = false;
     const size_t tb = sizeof(double) * (size_t)t->R * t->ld;
     LPX_HIP_TRY(hipMemcpyAsync(t->T, t->snapT, tb, hipMemcpyDeviceToDevice, t->stream));
     LPX_HIP_TRY(hipMemcpyAsync(t->basis, t->snapBasis, sizeof(int32_t) * (t->R > 1 ? t->R - 1 : 1),
@@ -835,9 +839,171 @@ int group_complete(GroupRun& r)
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Fused group run (K4g, lpx_group_fused): ONE launch per step for the whole group -- update(k) of every live node out of place
+// beside select(k+1) of every live node -- and a live list instead of early-exit workgroups: between polls the host drops the
+// finished nodes from the grid.  Launches are eager (a launch costs the host ~5 us against a step of tens of microseconds on
+// the device, and the grid changes from poll to poll).  Every node needs its second tableau buffer (fused_buffers); a group in
+// which one does not get it runs on the two-launch kernels below.  LPX_GROUP_FUSED=0: never (diagnostic).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct FusedGroupBuf {
+    FusedParams* d = nullptr; FusedParams* h = nullptr;     // parameter records: device / pinned
+    DevState* hs = nullptr;                                  // pinned: initial states in, latest records out
+    DevState* ds = nullptr;                                  // device copy of the initial states
+    int* live_d = nullptr; int* live_h = nullptr;            // live list (two halves: launches of window w read half w & 1)
+    int* fresh_d = nullptr; int* fresh_h = nullptr;
+    int* cur_h = nullptr;                                    // pinned: index of every node's latest record
+    int cap = 0;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;
+};
+FusedGroupBuf g_fgroup;
+
+int fused_group_reserve(FusedGroupBuf& g, int count)
+{
+    if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (count <= g.cap) return 0;
+    hipFree(g.d); hipFree(g.ds); hipFree(g.live_d); hipFree(g.fresh_d);
+    if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs); if (g.live_h) hipHostFree(g.live_h);
+    if (g.fresh_h) hipHostFree(g.fresh_h); if (g.cur_h) hipHostFree(g.cur_h);
+    g = FusedGroupBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, g.stream, std::move(g.ev)};
+    const int c = count + 16;
+    LPX_HIP_TRY(hipMalloc((void**)&g.d, sizeof(FusedParams) * c));
+    LPX_HIP_TRY(hipMalloc((void**)&g.ds, sizeof(DevState) * c));
+    LPX_HIP_TRY(hipMalloc((void**)&g.live_d, sizeof(int) * 2 * c));
+    LPX_HIP_TRY(hipMalloc((void**)&g.fresh_d, sizeof(int) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(FusedParams) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.hs, sizeof(DevState) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.live_h, sizeof(int) * 2 * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.fresh_h, sizeof(int) * c));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.cur_h, sizeof(int) * c));
+    g.cap = c;
+    return 0;
+}
+
+// returns LPX_RESIDENT_RETRY when the group cannot take this path (nothing has been touched then)
+int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
+                    int* statuses, lpx_stats* stats, const DevState* inits, int min_active)
+{
+    static const bool enabled = [] { const char* e = std::getenv("LPX_GROUP_FUSED"); return !(e && e[0] == '0'); }();
+    if (!enabled || count < 1) return LPX_RESIDENT_RETRY;
+    for (int i = 0; i < count; ++i) if (ts[i]->fused_off) return LPX_RESIDENT_RETRY;
+    for (int i = 0; i < count; ++i) if (!fused_buffers(ts[i])) return LPX_RESIDENT_RETRY;
+    FusedGroupBuf& g = g_fgroup;
+    { int rc = fused_group_reserve(g, count); if (rc) return rc; }
+    const double t0 = now_ms();
+    int per_node = 1, nfresh = 0, batch = 64;
+    long long budget = 0;
+    for (int k = 0; k < count; ++k) {
+        lpx_tableau* t = ts[k];
+        LPX_HIP_TRY(hipStreamSynchronize(t->stream));               // node assembly ran on the node's own stream
+        const lpx_run_opts* o = dual[k] ? dopts : popts;
+        FusedParams f; std::memset(&f, 0, sizeof(f));
+        f.P = base_params(t, o, dual[k] ? MODE_DUAL : MODE_PRIMAL);
+        f.T1 = t->fT; f.prow1 = t->fprow; f.rhs1 = t->frhs; f.rec = t->frec;
+        const bool cont = t->fsuspended;                            // continues a fused run: its records are in place
+        f.par = cont ? (t->frec_cur & 1) : 0;
+        g.h[k] = f;
+        DevState init; std::memset(&init, 0, sizeof(init));
+        init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = dual[k] ? 0 : 2;
+        if (inits) {                                                // continue where another path stopped (pivot count, phase, counters)
+            const DevState& s0 = inits[k];
+            init.iter = s0.iter; init.phase = dual[k] ? s0.phase : 2;
+            init.fdf_count = s0.fdf_count; init.dual_iter = s0.dual_iter; init.primal_count = s0.primal_count;
+        }
+        g.hs[k] = init;
+        if (!cont) g.fresh_h[nfresh++] = k;
+        t->fsuspended = false;
+        per_node = std::max(per_node, group_fused_blocks(t->ld, t->Rcap));
+        batch = o->batch > 0 ? o->batch : 64;
+        budget = std::max(budget, dual[k] ? (long long)o->fdf_guard + 2LL * o->max_iter + 12 : (long long)o->max_iter + 6);
+    }
+    batch = (batch + 1) & ~1;           // launches alternate between the two record indices: a window ends where it started
+    LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(FusedParams) * count, hipMemcpyHostToDevice, g.stream));
+    if (nfresh > 0) {
+        LPX_HIP_TRY(hipMemcpyAsync(g.ds, g.hs, sizeof(DevState) * count, hipMemcpyHostToDevice, g.stream));
+        LPX_HIP_TRY(hipMemcpyAsync(g.fresh_d, g.fresh_h, sizeof(int) * nfresh, hipMemcpyHostToDevice, g.stream));
+        LPX_HIP_TRY(launch_group_fused_init(g.d, g.fresh_d, nfresh, g.ds, g.stream));
+    }
+    std::vector<int> live(count);
+    for (int k = 0; k < count; ++k) live[k] = k;
+    long long enq = 0; int window = 0; bool suspended_exit = false;
+    const bool profile = popts->profile || dopts->profile;      // every launch bracketed by HIP events bound to the dispatch
+    double prof_ms = 0.0; long long prof_n = 0;
+    if (profile) while ((int)g.ev.size() < 2 * batch) { hipEvent_t e; LPX_HIP_TRY(hipEventCreate(&e)); g.ev.push_back(e); }
+    while (!live.empty() && enq < budget) {
+        // this window's live list (its own half of the buffer: the previous window's launches may still be reading theirs -- they
+        // are not, the poll below waits, but the copy stays safe if the loop ever runs ahead)
+        int* lh = g.live_h + (window & 1) * g.cap; int* ld_ = g.live_d + (window & 1) * g.cap;
+        size_t live_bytes = 0;
+        for (size_t k = 0; k < live.size(); ++k) { lh[k] = live[k]; const lpx_tableau* t = ts[live[k]]; live_bytes += sizeof(double) * (size_t)t->R * t->ld; }
+        LPX_HIP_TRY(hipMemcpyAsync(ld_, lh, sizeof(int) * live.size(), hipMemcpyHostToDevice, g.stream));
+        for (int i = 0; i < batch; ++i)
+            LPX_HIP_TRY(launch_group_fused(g.d, ld_, (int)live.size(), per_node, (int)((enq + i) & 1), live_bytes, g.stream,
+                                           profile ? g.ev[2 * i] : nullptr, profile ? g.ev[2 * i + 1] : nullptr));
+        enq += batch;
+        LPX_HIP_TRY(launch_group_fused_gather(g.d, count, g.hs, g.cur_h, g.stream));
+        LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+        if (profile) {
+            // launches that applied a pivot of at least one node: those up to the largest pivot count of the window's live nodes
+            int full = 0;
+            for (int k : live) full = std::max(full, g.hs[k].iter);
+            const long long first = enq - batch;                   // launch l applies pivot l (the first launch of a run applies none)
+            for (int i = 0; i < batch; ++i) {
+                if (first + i < 1 || first + i > full) continue;
+                float msf = 0.f;
+                LPX_HIP_TRY(hipEventElapsedTime(&msf, g.ev[2 * i], g.ev[2 * i + 1]));
+                prof_ms += msf; ++prof_n;
+            }
+        }
+        ++window;
+        std::vector<int> next;
+        for (int k : live) if (g.hs[k].status == LPX_RUNNING) next.push_back(k);
+        live.swap(next);
+        if (!live.empty() && min_active > 0 && (int)live.size() <= min_active) { suspended_exit = true; break; }
+    }
+    const double ms = now_ms() - t0;
+    for (int k = 0; k < count; ++k) {
+        lpx_tableau* t = ts[k];
+        const DevState& s = g.hs[k];
+        *t->hst = s;
+        const bool running = s.status == LPX_RUNNING;
+        statuses[k] = running ? (suspended_exit ? LPX_RUNNING : LPX_ITER_LIMIT) : s.status;
+        t->suspended = statuses[k] == LPX_RUNNING;
+        t->fsuspended = t->suspended;
+        t->frec_cur = g.cur_h[k];
+        // a finished node whose last pivot landed in the second buffer: the buffers trade places (every consumer -- solution
+        // read-back, parking, child assembly, download -- goes through t->T); an unfinished one keeps its pending pivot where it is
+        if (!running && s.pad[3] == 1) { std::swap(t->T, t->fT); drop_graph(t); }
+        if (stats) {
+            const double h2d = stats[k].h2d_ms, d2h = stats[k].d2h_ms;      // one-shot entry points keep their transfer times here
+            std::memset(&stats[k], 0, sizeof(lpx_stats));
+            stats[k].h2d_ms = h2d; stats[k].d2h_ms = d2h;
+            stats[k].pivots = s.iter; stats[k].fdf_pivots = s.fdf_count;
+            stats[k].cleanup_pivots = dual[k] ? s.primal_count : 0;
+            stats[k].loop_ms = ms / (double)count;
+            stats[k].launches = enq / (long long)count + 1;
+            if (k == 0) { stats[k].update_ms_sum = prof_ms; stats[k].update_launches = prof_n; }   // group-level figures
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
 static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
                              const lpx_run_opts* dopts, int* statuses, lpx_stats* stats, const DevState* inits = nullptr, int min_active = 0)
 {
+    {   // one launch per step when every node has its second buffer (and none is in the middle of a two-launch run)
+        bool any_two_launch = false;
+        for (int i = 0; i < count; ++i) if (ts[i]->suspended2) any_two_launch = true;
+        if (!any_two_launch) {
+            const int rc = multi_run_fused(ts, dual, count, popts, dopts, statuses, stats, inits, min_active);
+            if (rc != LPX_RESIDENT_RETRY) return rc;
+        }
+    }
     GroupRun runs[2];
     for (int w = 0; w < 2; ++w) { runs[w].g = &g_groups[w]; runs[w].dual = w; runs[w].min_active = min_active; }
     for (int i = 0; i < count; ++i) runs[dual[i] ? 1 : 0].idx.push_back(i);
@@ -858,6 +1024,7 @@ static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const
             *ts[i]->hst = s;
             statuses[i] = s.status == LPX_RUNNING ? (r.suspended_exit ? LPX_RUNNING : LPX_ITER_LIMIT) : s.status;
             ts[i]->suspended = statuses[i] == LPX_RUNNING;          // continues from *hst in the next lpx_multi_run_some
+            ts[i]->suspended2 = ts[i]->suspended;
             if (stats) {
                 std::memset(&stats[i], 0, sizeof(lpx_stats));
                 stats[i].pivots = s.iter; stats[i].fdf_pivots = s.fdf_count;
@@ -928,6 +1095,11 @@ int lpx_dual_run(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
         } else
         if (o->resident > 0) { set_error("lpx_dual_run: resident = 1 but the tableau does not fit the chip's LDS"); return LPX_EINVAL; }
     }
+    if (!cb) {          // no per-pivot callback: one launch per step (lpx_group_fused, a group of one), update out of place
+        int isdual = 1, status = 0;
+        const int rc = multi_run_fused(&t, &isdual, 1, o, o, &status, st, nullptr, 0);
+        if (rc != LPX_RESIDENT_RETRY) return rc ? rc : status;
+    }
     SelParams p = base_params(t, o, MODE_DUAL);
     long long budget = (long long)o->fdf_guard + 2LL * o->max_iter + 8;
     return run_loop(t, p, o, budget, cb, user, st);
@@ -991,7 +1163,7 @@ int lpx_tableau_set_shape(lpx_tableau* t, int R, int C)
 {
     if (!t || R < 1 || C < 2 || R > t->Rcap || C > t->Ccap) { set_error("lpx_tableau_set_shape: shape outside the handle's capacity"); return LPX_EINVAL; }
     LPX_HIP_TRY(hipStreamSynchronize(t->stream));          // the pinned staging word may still be in flight
-    t->R = R; t->C = C; t->suspended = false;               // a new tableau is coming: nothing to continue
+    t->R = R; t->C = C; t->suspended = t->suspended2 = t->fsuspended = false;               // a new tableau is coming: nothing to continue
     t->shape_h[0] = R; t->shape_h[1] = C;
     LPX_HIP_TRY(hipMemcpyAsync(t->shape, t->shape_h, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
     return 0;
@@ -1072,7 +1244,7 @@ int lpx_tableau_build_nodes(lpx_tableau** nodes, const lpx_tableau* root, int co
     for (int i = 0; i < count; ++i) {
         lpx_tableau* t = nodes[i];
         const int nc = cut_off[i + 1] - cut_off[i];
-        t->R = root->R + nc; t->C = root->C + nc; t->suspended = false;
+        t->R = root->R + nc; t->C = root->C + nc; t->suspended = t->suspended2 = t->fsuspended = false;
         t->shape_h[0] = t->R; t->shape_h[1] = t->C;
         d[i].T = t->T; d[i].basis = t->basis; d[i].shape = t->shape; d[i].st = t->st; d[i].ld = t->ld; d[i].R = t->R; d[i].C = t->C; d[i].cut0 = cut_off[i];
     }
@@ -1239,7 +1411,7 @@ int lpx_tableau_build_children_from_store(lpx_tableau** children, lpx_store** st
     for (int i = 0; i < count; ++i) {
         lpx_tableau* ch = children[i]; lpx_store* s = stores[i]; const int slot = slots[i];
         const int Rp = s->R[slot], Cp = s->C[slot];
-        ch->R = Rp + 1; ch->C = Cp + 1; ch->suspended = false; ch->shape_h[0] = ch->R; ch->shape_h[1] = ch->C;
+        ch->R = Rp + 1; ch->C = Cp + 1; ch->suspended = ch->suspended2 = ch->fsuspended = false; ch->shape_h[0] = ch->R; ch->shape_h[1] = ch->C;
         d[i].Tp = store_T(s, slot); d[i].basis_p = store_b(s, slot); d[i].T = ch->T; d[i].basis = ch->basis; d[i].shape = ch->shape; d[i].st = ch->st;
         d[i].ldp = s->ld; d[i].Rp = Rp; d[i].Cp = Cp; d[i].ld = ch->ld; d[i].var = var[i]; d[i].ik = row_of_var[i]; d[i].is_ge = is_ge[i] ? 1 : 0; d[i].pad = 0;
         d[i].bound = bound[i];

@@ -100,6 +100,16 @@ def main():
         r = L.BranchAndBound(bnb_mode=1, rank=rank, world=world, allreduce_max=allreduce_max, **kw).Solve(ps)
         res[name] = {"z": r.OptimalValue, "x": np.asarray(r.Solution).tolist() if r.Solution is not None else None,
                      "lp_solves": r.LpSolves, "nodes": r.Nodes, "allreduces": calls["n"], "aux": list(r.Aux)}
+    # a mid-size 0/1 IP whose node tableaux (121 x 217 f64 = 205 KB) do not fit one CU's LDS, SOLVED by the sharded level search:
+    # incumbents appear on both ranks, the all-reduced bound prunes, pools are rebalanced (tests/golden/bnb_mid.json has the
+    # oracle's reference-order DFS optimum and HiGHS's)
+    cm, Am, relm, bm = synth.binary_ip(96, 24)
+    pm = L.LPProblem.from_arrays(0, cm, Am, relm, bm)
+    calls["n"] = 0
+    rm = L.BranchAndBound(bnb_mode=1, bnb_search=1, bnb_dive=1, concurrent_nodes=64, rank=rank, world=world, allreduce_max=allreduce_max).Solve(pm)
+    logm = np.asarray(rm.NodeLog).reshape(-1, 3)
+    res["mid"] = {"z": rm.OptimalValue, "x": np.asarray(rm.Solution).tolist(), "lp_solves": rm.LpSolves, "aux": list(rm.Aux), "allreduces": calls["n"],
+                  "pruned": int((logm[:, 1] == 3).sum()), "incumbents": int((logm[:, 1] == 4).sum())}
     # knapsack solved to exhaustion through the device node store (evaluated tree re-seeded after the split)
     g = np.random.default_rng(3)
     n = 300

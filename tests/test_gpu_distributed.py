@@ -97,6 +97,19 @@ def test_two_ranks_on_one_gpu_agree_with_the_single_rank_search(gpu, oracle, tmp
         assert a["x"] == b["x"], name                                     # ... and the same solution vector
         assert abs(np.asarray(a["x"]) @ cs - a["z"]) <= 1e-9 * max(1.0, abs(a["z"]))
         assert a["allreduces"] == b["allreduces"] >= 1 and a["aux"][0] == b["aux"][0]      # same levels, same collectives
+    # the mid-size IP (node tableaux larger than one CU's LDS): the optimum of the oracle's reference-order DFS (28 122 node LPs, a
+    # minute of CPU: tests/golden/bnb_mid.json, made by tests/golden/gen_bnb_mid.py) and of HiGHS, on both ranks, with the shared
+    # bound at work -- incumbents found, nodes pruned by it, the work split
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bnb_mid.json")))["96x24"]
+    cm, Am, relm, bm = synth.binary_ip(96, 24)
+    a, b = res[0]["mid"], res[1]["mid"]
+    assert a["z"] == b["z"] == gold["dfs_z"] and abs(a["z"] - gold["highs_z"]) <= 1e-9 * gold["highs_z"]
+    assert a["x"] == b["x"] and set(a["x"]) <= {0.0, 1.0}
+    xm = np.asarray(a["x"])
+    assert float(xm @ cm) == a["z"] and (Am @ xm <= bm + 1e-9).all()
+    assert a["allreduces"] == b["allreduces"] >= 10 and a["aux"][0] == b["aux"][0]
+    assert a["incumbents"] + b["incumbents"] >= 2 and a["pruned"] + b["pruned"] >= 1000
+    assert min(a["lp_solves"], b["lp_solves"]) >= 0.25 * max(a["lp_solves"], b["lp_solves"])
     g = np.random.default_rng(3)
     n = 300
     w = g.integers(1, 60, size=n).astype(float); p = w + g.integers(0, 12, size=n)
