@@ -206,6 +206,16 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
 int lpx_multi_run_some(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
                        const lpx_run_opts* dual_opts, int* statuses, lpx_stats* stats /* [count] or NULL */, int min_active);
 
+/* The same in two halves, for hosts that keep TWO rolling batches (slot 0 and 1) so that one pivots while the other is read
+ * back, decided on and refilled: _begin enqueues `steps` pivots (rounded up to even) of every run of the batch -- fresh
+ * tableaux and runs a previous window left as LPX_RUNNING alike -- on the slot's own stream and returns at once; _end waits for
+ * that window and reports as lpx_multi_run_some does (LPX_RUNNING = unfinished, hand it in again).  Between the two calls the
+ * batch's handles must not be touched.  _begin returns 1 (nothing enqueued) when the one-launch-per-step kernels cannot take
+ * the batch (a second tableau buffer did not fit, profile mode): use lpx_multi_run_some then. */
+int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
+                        const lpx_run_opts* dual_opts, int steps);
+int lpx_multi_run_end(int slot, int* statuses, lpx_stats* stats /* [count of the _begin] or NULL */);
+
 /* ---- one-shot entry points on host buffers (what the C# shim binds) -------------------------- */
 /* Replaces the loop of PrimalSimplex.Solve (Models/PrimalSimplex.cs:92-124) on the `double[,]`
  * built by BuildTableau (:179-203).  T and basis are updated in place. */

@@ -179,6 +179,8 @@ def lib() -> C.CDLL:
                                 C.POINTER(C.c_int), C.POINTER(Stats)]
     L.lpx_multi_run_some.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts),
                                      C.POINTER(C.c_int), C.POINTER(Stats), C.c_int]
+    L.lpx_multi_run_begin.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.POINTER(RunOpts), C.POINTER(RunOpts), C.c_int]
+    L.lpx_multi_run_end.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(Stats)]
     L.lpx_knapsack_create.argtypes = [dp, dp, C.c_int, C.c_double, C.POINTER(vp)]
     L.lpx_knapsack_destroy.argtypes = [vp]
     L.lpx_knapsack_destroy.restype = None

@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <atomic>
+#include <thread>
 
 namespace lpx { namespace host {
 
@@ -100,6 +102,8 @@ struct NodeLP {
     lpx_store* pstore = nullptr; int pslot = -1; int prow = -1; bool warm = false; bool keep = false;   // keep: park the result
     lpx_store* kstore = nullptr; int kslot = -1; std::vector<int32_t> basis_out;
     double wbound = 0.0; bool wis_ge = false; int wslot = 0; int depth = 0;
+    int feas = -1;          // IsFeasible(x) of :175-179 when it has been evaluated ahead of decide() (precompute_feas): 0 / 1
+    const std::vector<Cut>* cuts_for_feas = nullptr;   // the node's branching rows, when solve_group may evaluate `feas` itself
 };
 
 // index of the root constraints for the per-node feasibility test (IsFeasibleIndexed below)
@@ -407,7 +411,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         for (NodeLP* lp : group) node_bytes = std::max(node_bytes, sizeof(double) * (size_t)lp->R * (size_t)lp->C);
         if (node_bytes > ((size_t)1 << 20)) {
             dopt.resident = -1; po.resident = -1; rolling = group.size() > 1;
-            static const int roll_batch = [] { const char* e = std::getenv("LPX_ROLL_BATCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 32; }();   // pivots between polls
+            static const int roll_batch = [] { const char* e = std::getenv("LPX_ROLL_BATCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 16; }();   // pivots between polls
             if (rolling && c.opt.batch <= 0) dopt.batch = po.batch = roll_batch;
         }
     }
@@ -469,11 +473,76 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         g_pt.build += PhaseTimer::now() - t0;
     };
     if (rolling) {
-        // ROLLING batch (warm-started children on the streaming kernels): most of them need a few dozen pivots, a few need hundreds.
-        // A run stops when only half of the batch is still going (lpx_multi_run_some, polled every 32 pivots); those stay, fresh nodes fill the
-        // batch up, and nobody waits at the per-step latency floor for the slowest node of a fixed batch.
+        // ROLLING batches (warm-started children on the streaming kernels): most of them need a few dozen pivots, a few need hundreds.
+        // TWO batches of `width` nodes alternate (lpx_multi_run_begin / _end): while one pivots through a window of `roll_batch`
+        // steps, the host reads the other one's finished nodes back, parks their tableaux, tests their solutions and assembles fresh
+        // children in their places -- so the device never waits for the host and finished nodes leave the grid after every window.
+        static const bool pipelined = [] { const char* e = std::getenv("LPX_ROLL_PIPELINE"); return !(e && e[0] == '0'); }();   // diagnostic: 0 = one batch, synchronous
         size_t next = 0;
+        const int steps = dopt.batch > 0 ? dopt.batch : 16;
+        struct Set { std::vector<NodeLP*> inflight; bool running = false; };
+        Set sets[2];
+        bool async_ok = pipelined;
+        auto launch = [&](int s) {
+            Set& S = sets[s];
+            std::vector<NodeLP*> fresh;
+            while (next < group.size() && S.inflight.size() + fresh.size() < width) fresh.push_back(group[next++]);
+            if (c.count_work) c.out->LpSolves += (int64_t)fresh.size();
+            admit(fresh, S.inflight);
+            if (S.inflight.empty()) return;
+            std::vector<lpx_tableau*> hs; std::vector<int> dual;
+            for (NodeLP* lp : S.inflight) { hs.push_back(lp->h); dual.push_back(lp->dual ? 1 : 0); }
+            const int rc = lpx_multi_run_begin(s, hs.data(), dual.data(), (int)hs.size(), &po, &dopt, steps);
+            if (rc < 0) throw LpxException(rc, "liblpx: " + last_error());
+            if (rc == 1) { async_ok = false; return; }               // not available: the synchronous loop below takes what is in the sets
+            S.running = true;
+        };
+        auto land = [&](int s) {
+            Set& S = sets[s];
+            std::vector<int> st(S.inflight.size()); std::vector<lpx_stats> ss(S.inflight.size());
+            double t0 = PhaseTimer::now();
+            const int rc = lpx_multi_run_end(s, st.data(), ss.data());
+            g_pt.run += PhaseTimer::now() - t0;
+            S.running = false;
+            if (rc) throw LpxException(rc, "liblpx: " + last_error());
+            std::vector<NodeLP*> fin, keep; std::vector<int> fst; std::vector<lpx_stats> fss;
+            for (size_t i = 0; i < S.inflight.size(); ++i) {
+                if (st[i] == LPX_RUNNING) keep.push_back(S.inflight[i]);
+                else { fin.push_back(S.inflight[i]); fst.push_back(st[i]); fss.push_back(ss[i]); }
+            }
+            t0 = PhaseTimer::now();
+            collect_group(c, fin, fst, fss, nvars);                  // pivots are cumulative per node: counted once, when it finishes
+            // the feasibility test of :175-179 for the finished nodes, here where the other batch's window hides it
+            if (c.feas.built || !fin.empty()) {
+                if (!c.feas.built) c.feas.build(*c.root);
+                for (NodeLP* lp : fin)
+                    if (lp->cuts_for_feas && !lp->error && lp->has_solution && !(c.opt.bnb_mode == 1 && lp->status == LPX_INFEASIBLE))
+                        lp->feas = IsFeasibleIndexed(lp->x, *c.root, *lp->cuts_for_feas, c.feas) ? 1 : 0;
+            }
+            g_pt.collect += PhaseTimer::now() - t0;
+            S.inflight.swap(keep);
+        };
+        if (async_ok) {
+            try {
+                launch(0);
+                if (async_ok) launch(1);
+                while (async_ok && (sets[0].running || sets[1].running))
+                    for (int s = 0; s < 2 && async_ok; ++s) {
+                        if (!sets[s].running) continue;
+                        land(s);
+                        launch(s);
+                    }
+            } catch (...) {
+                // a window may still be in flight in the other slot: wait for it before the handles go back to the pool
+                for (int s = 0; s < 2; ++s) if (sets[s].running) { std::vector<int> st(sets[s].inflight.size()); lpx_multi_run_end(s, st.data(), nullptr); sets[s].running = false; }
+                throw;
+            }
+            if (async_ok) return;
+            for (int s = 0; s < 2; ++s) if (sets[s].running) land(s);
+        }
+        // synchronous form (one batch; also what is left when the two-slot path was not available)
         std::vector<NodeLP*> inflight;
+        for (int s = 0; s < 2; ++s) { inflight.insert(inflight.end(), sets[s].inflight.begin(), sets[s].inflight.end()); sets[s].inflight.clear(); }
         while (next < group.size() || !inflight.empty()) {
             std::vector<NodeLP*> fresh;
             while (next < group.size() && inflight.size() + fresh.size() < width) fresh.push_back(group[next++]);
@@ -521,6 +590,41 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     }
 }
 
+// The feasibility test of :175-179 for a whole level ahead of the decisions: it is a pure function of a node's x (768 rows x 512
+// columns at config 4: ~15 us per node, a tenth of the warm-started leg when done one node at a time between the device
+// batches), so the nodes of a level are tested on a few host threads; decide() then takes the verdict from NodeLP::feas.  Order
+// of the decisions, logs and incumbent updates is untouched.  LPX_HOST_THREADS=n (default: up to 8; 1 = off).
+template <class FN>
+void precompute_feas(Ctx& c, std::vector<NodeLP>& lps, const std::vector<FN>& frontier, const std::vector<char>& skip)
+{
+    static const int nthreads = [] {
+        const char* e = std::getenv("LPX_HOST_THREADS"); int v = e ? std::atoi(e) : 0;
+        if (v <= 0) { v = (int)std::thread::hardware_concurrency(); if (v > 8) v = 8; }
+        return v < 1 ? 1 : v; }();
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < lps.size(); ++i) {
+        const NodeLP& lp = lps[i];
+        if (skip[i] || lp.error || !lp.has_solution || lp.feas >= 0 || (c.opt.bnb_mode == 1 && lp.status == LPX_INFEASIBLE)) continue;
+        todo.push_back(i);
+    }
+    if (nthreads < 2 || todo.size() < 64) return;
+    if (!c.feas.built) c.feas.build(*c.root);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= todo.size()) break;
+            const size_t i = todo[k];
+            lps[i].feas = IsFeasibleIndexed(lps[i].x, *c.root, frontier[i].cuts, c.feas) ? 1 : 0;
+        }
+    };
+    std::vector<std::thread> pool;
+    const int n = std::min<int>(nthreads, (int)(todo.size() / 32) + 1);
+    for (int t = 1; t < n; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& th : pool) th.join();
+}
+
 void node_log(Ctx& c, int depth, int outcome, int var, double z)
 {
     c.out->NodeLog.push_back(depth); c.out->NodeLog.push_back(outcome); c.out->NodeLog.push_back(var);
@@ -554,7 +658,7 @@ int decide(Ctx& c, const std::vector<Cut>& cuts, const NodeLP& lp, int depth, co
     if (c.opt.bnb_mode == 1 && lp.status == LPX_INFEASIBLE) { node_log(c, depth, O_LP_INFEASIBLE, -1, lp.z); return -1; }
     const std::vector<double>& x = lp.x; const double z = lp.z;
     if (c.cb) c.log(name + " LP solution: z* = " + FormatF(z, 3));
-    if (!IsFeasibleIndexed(x, *c.root, cuts, c.feas)) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
+    if (!(lp.feas >= 0 ? lp.feas == 1 : IsFeasibleIndexed(x, *c.root, cuts, c.feas))) { c.log(name + ": Solution is infeasible for constraints."); node_log(c, depth, O_INFEASIBLE_X, -1, z); return -1; }   // :175-179
     const double bestObj = c.has_best ? c.best : -INFINITY;
     // Sharded searches visit nodes level by level, not in the reference's depth-first order.  Among integer nodes with
     // EXACTLY the incumbent's z the one the reference's DFS reaches first keeps the solution vector (first found wins
@@ -711,6 +815,7 @@ void LevelSearch(Ctx& c)
             for (size_t i = 0; i < frontier.size(); ++i) if (!skip[i]) skip[i] = 1;
         }
         std::vector<FNode> next;
+        precompute_feas(c, lps, frontier, skip);
         for (size_t i = 0; i < frontier.size(); ++i) {
             if (skip[i] == 1) continue;
             if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }
@@ -891,12 +996,14 @@ void WarmSearch(Ctx& c)
             lp.pstore = frontier[i].store; lp.pslot = frontier[i].slot; lp.prow = frontier[i].prow;
             lp.cvar.push_back(k.var); lp.wis_ge = (k.rel == Rel::GE); lp.wbound = k.bound;
             lp.R = c.tplR[w] + frontier[i].depth; lp.C = c.tplC[w] + frontier[i].depth;
+            lp.cuts_for_feas = &frontier[i].cuts;
             group.push_back(&lp);
         }
         std::vector<WNode> next;
         try {
             solve_group(c, group, nvars);
             for (const WNode& f : frontier) unref(f.store, f.slot);      // every child of this level is built
+            { const double t0 = PhaseTimer::now(); precompute_feas(c, lps, frontier, skip); g_pt.decide += PhaseTimer::now() - t0; }
             for (size_t i = 0; i < frontier.size(); ++i) {
                 if (skip[i] == 1) continue;
                 if (skip[i] == 2) { node_log(c, frontier[i].depth, O_DEPTH, -1, 0.0); continue; }

@@ -81,8 +81,12 @@ hipError_t launch_pivot_fused(const FusedParams& f, int par, hipStream_t s, hipE
 hipError_t launch_group_fused_init(const FusedParams* arr, const int* fresh, int nfresh, const DevState* init, hipStream_t s);
 hipError_t launch_group_fused_gather(const FusedParams* arr, int count, DevState* out, int* cur, hipStream_t s);
 int group_fused_blocks(int ld, int R);
+// comp: the group's device-side compaction record (group_fused_comp_ints(cap) ints; the host writes count and list of parity 0 before
+// the first launch of a window, the kernel keeps them current from launch to launch)
+int group_fused_comp_ints(int cap);
+int group_fused_comp_hdr();     // ints in front of the list of a parity region: {count, padding}
 hipError_t launch_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, size_t live_bytes, hipStream_t s,
-                              hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                              int* comp, int cap, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_states_scatter(const SelParams* arr, const DevState* src_pinned, int count, hipStream_t s);
 hipError_t launch_states_gather(const SelParams* arr, DevState* dst_pinned, int count, hipStream_t s);
 hipError_t launch_group_iter(const SelParams* arr, int count, int dual, int max_nblk, int max_upd_blocks, hipStream_t s,

@@ -1384,18 +1384,34 @@ __global__ __launch_bounds__(64) void lpx_group_fused_gather(const FusedParams* 
     if (threadIdx.x == 0) cur[blockIdx.x] = which;
 }
 
+// device-side compaction record of a group (ints): the live list the update workgroups of launch L go by was written by the last
+// select workgroup of launch L - 1 (or by the host for the first launch of a window), double-buffered on the launch parity
+// layout: [parity 0: count, 15 pad, list[cap]] [parity 1: the same] [arrival counter of the select workgroups, 15 pad] [flags[cap]: "slot s goes on"]
+static constexpr int FG_COMP_HDR = 16;
+__host__ __device__ constexpr int fg_comp_region(int cap) { return FG_COMP_HDR + cap; }
+
 template <bool NT>
 __device__ __forceinline__ void lpx_group_fused_body(const FusedParams* __restrict__ arr, const int* __restrict__ live, int nlive,
-                                                     int per_node, int lpar, int mixmod)
+                                                     int per_node, int lpar, int mixmod, const int* __restrict__ comp_rd, int* comp, int cap)
 {
     __shared__ double s_v[FG_NT / 64];
     __shared__ int s_i[FG_NT / 64];
     const int t = threadIdx.x;
     const int bid = blockIdx.x;
     const bool is_select = bid < nlive;
-    const int slot = is_select ? bid : (bid - nlive) / per_node;
-    const int ublk = is_select ? 0 : (bid - nlive) % per_node;
-    const int node = __builtin_amdgcn_readfirstlane(live[slot]);      // workgroup-uniform: the record below stays in scalar registers
+    const int par = lpar & 1;
+    int node, ublk = 0;
+    if (is_select) node = __builtin_amdgcn_readfirstlane(live[bid]);
+    else {
+        // update workgroups take their node from the DEVICE's live list: nodes that finished in an earlier launch of this window have
+        // left it, and the workgroups beyond the live ones (the tail of the grid) leave after one load
+        // (comp_rd = this launch's parity region, read-only in this launch: scalar loads; the kernel writes the other region through `comp`)
+        const int u = bid - nlive;
+        const int n_dev = comp_rd[0];
+        if (u >= n_dev * per_node) return;
+        node = comp_rd[FG_COMP_HDR + u / per_node];
+        ublk = u % per_node;
+    }
     const FusedParams F = arr[node];
     const SelParams& P = F.P;
     const int c = (lpar ^ F.par) & 1;
@@ -1470,10 +1486,11 @@ __device__ __forceinline__ void lpx_group_fused_body(const FusedParams* __restri
     }
 
     // ---------------- select(k+1) on T_{k+1}, read as T_k with pivot k's correction ----------------
+    auto select = [&]() -> int {        // returns 1 while the node goes on (a pivot is pending for the next launch)
     const int nbuf = pr >= 0 ? (buf ^ 1) : buf;              // where T_{k+1} lives once this launch is over
     if (status != LPX_RUNNING) {
         if (t == 0) { DevState x = *curp; x.pad[2] = seq + 1; *nxt = x; }
-        return;
+        return 0;
     }
     double* __restrict__ prown = c ? P.prow : F.prow1;
     double* __restrict__ facn = c ? P.col0 : P.col1;
@@ -1574,7 +1591,7 @@ __device__ __forceinline__ void lpx_group_fused_body(const FusedParams* __restri
             x.phase = phase; x.r = -1; x.q = -1; x.qn = -1; x.pad[2] = seq + 1; x.pad[3] = nbuf;
             *nxt = x;
         }
-        return;
+        return 0;
     }
     // pivot prep (Models/PrimalSimplex.cs:249-250): the normalised pivot row of pivot k+1, true division
     if (!have_row) row(r, false);
@@ -1592,12 +1609,45 @@ __device__ __forceinline__ void lpx_group_fused_body(const FusedParams* __restri
         x.pad[2] = seq + 1; x.pad[3] = nbuf;
         *nxt = x;
     }
+    return 1;
+    };
+    const int alive = select();
+    // ---- compaction for the NEXT launch: the last select workgroup to get here writes the list of the nodes that go on.  Hand-off as in
+    //      lpx_select_mb: an agent-scope store of this slot's flag, wait for it, ONE agent-scope add; the workgroup whose add returns
+    //      nlive - 1 reads the flags with agent-scope loads.  Nothing of index `par` is written here; the update workgroups read only that.
+    if (t < 64) {
+        int* arrive = comp + 2 * fg_comp_region(cap);
+        int* flags = arrive + FG_COMP_HDR;
+        int last = 0;
+        if (t == 0) {
+            __hip_atomic_store(&flags[bid], alive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = (__hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nlive - 1) ? 1 : 0;
+        }
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (last) {
+            int* outr = comp + (par ^ 1) * fg_comp_region(cap);
+            int* out = outr + FG_COMP_HDR;
+            int k = 0;
+            for (int s0 = 0; s0 < nlive; s0 += 64) {
+                const int sidx = s0 + t;
+                const int f = sidx < nlive ? __hip_atomic_load(&flags[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                const unsigned long long mk = __ballot(f != 0);
+                if (f) out[k + __popcll(mk & ((1ull << t) - 1ull))] = live[sidx];
+                k += __popcll(mk);
+            }
+            if (t == 0) {
+                outr[0] = k;
+                __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
-__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod)
-{ lpx_group_fused_body<true>(arr, live, nlive, per_node, lpar, mixmod); }
-__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused_c(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod)
-{ lpx_group_fused_body<false>(arr, live, nlive, per_node, lpar, mixmod); }
+__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod, const int* comp_rd, int* comp, int cap)
+{ lpx_group_fused_body<true>(arr, live, nlive, per_node, lpar, mixmod, comp_rd, comp, cap); }
+__global__ __launch_bounds__(FG_NT) __attribute__((amdgpu_waves_per_eu(6))) void lpx_group_fused_c(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, int mixmod, const int* comp_rd, int* comp, int cap)
+{ lpx_group_fused_body<false>(arr, live, nlive, per_node, lpar, mixmod, comp_rd, comp, cap); }
 
 hipError_t launch_group_fused_init(const FusedParams* arr, const int* fresh, int nfresh, const DevState* init, hipStream_t s)
 {
@@ -1618,8 +1668,10 @@ int group_fused_blocks(int ld, int R)
 }
 // live_bytes: tableau bytes of the live nodes (one buffer each): both buffers of the group at home in the Infinity Cache ->
 // default policy; beyond that nontemporal loads and the mixed store policy of lpx_pivot_fused
+int group_fused_comp_ints(int cap) { return 3 * fg_comp_region(cap); }
+int group_fused_comp_hdr() { return FG_COMP_HDR; }
 hipError_t launch_group_fused(const FusedParams* arr, const int* live, int nlive, int per_node, int lpar, size_t live_bytes, hipStream_t s,
-                              hipEvent_t e0, hipEvent_t e1)
+                              int* comp, int cap, hipEvent_t e0, hipEvent_t e1)
 {
     if (nlive <= 0) return hipSuccess;
     static const int forced = [] { const char* e = std::getenv("LPX_UPDATE_POLICY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
@@ -1629,8 +1681,9 @@ hipError_t launch_group_fused(const FusedParams* arr, const int* live, int nlive
     const int mixmod = pol == 2 ? (mm_forced > 0 ? mm_forced : (int)((live_bytes + UPD_MIX_STEP_BYTES - 1) / UPD_MIX_STEP_BYTES)) : 0;
     auto kern = pol == 0 ? lpx_group_fused_c : lpx_group_fused;
     const unsigned nblocks = (unsigned)nlive * (unsigned)(1 + per_node);
-    if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, e0, e1, 0, arr, live, nlive, per_node, lpar & 1, mixmod);
-    else hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, arr, live, nlive, per_node, lpar & 1, mixmod);
+    const int* comp_rd = comp + (lpar & 1) * fg_comp_region(cap);
+    if (e0 && e1) hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, e0, e1, 0, arr, live, nlive, per_node, lpar & 1, mixmod, comp_rd, comp, cap);
+    else hipLaunchKernelGGL(kern, dim3(nblocks), dim3(FG_NT), 0, s, arr, live, nlive, per_node, lpar & 1, mixmod, comp_rd, comp, cap);
     return hipGetLastError();
 }
 

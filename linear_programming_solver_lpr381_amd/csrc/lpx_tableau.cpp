@@ -853,22 +853,33 @@ struct FusedGroupBuf {
     DevState* hs = nullptr;                                  // pinned: initial states in, latest records out
     DevState* ds = nullptr;                                  // device copy of the initial states
     int* live_d = nullptr; int* live_h = nullptr;            // live list (two halves: launches of window w read half w & 1)
+    int* comp_d = nullptr; int* comp_h = nullptr;            // device-side compaction record (lpx_kernels.hip FG_COMP_*) and its pinned staging
     int* fresh_d = nullptr; int* fresh_h = nullptr;
     int* cur_h = nullptr;                                    // pinned: index of every node's latest record
     int cap = 0;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;
 };
-FusedGroupBuf g_fgroup;
 
 int fused_group_reserve(FusedGroupBuf& g, int count)
 {
-    if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (!g.stream) {
+        // LOWEST priority: a window is a dozen chip-filling launches in a row; the small launches the host needs answered while the
+        // other batch pivots (solution read-back, parking, child assembly: other streams, default priority) must get their
+        // workgroups in as slots free up instead of queueing behind the window (measured: they waited 1-2 ms each without this)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        if (hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        }
+    }
     if (count <= g.cap) return 0;
-    hipFree(g.d); hipFree(g.ds); hipFree(g.live_d); hipFree(g.fresh_d);
+    hipFree(g.d); hipFree(g.ds); hipFree(g.live_d); hipFree(g.fresh_d); hipFree(g.comp_d);
+    if (g.comp_h) hipHostFree(g.comp_h);
     if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs); if (g.live_h) hipHostFree(g.live_h);
     if (g.fresh_h) hipHostFree(g.fresh_h); if (g.cur_h) hipHostFree(g.cur_h);
-    g = FusedGroupBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, g.stream, std::move(g.ev)};
+    { hipStream_t st = g.stream; std::vector<hipEvent_t> ev = std::move(g.ev); g = FusedGroupBuf{}; g.stream = st; g.ev = std::move(ev); }
     const int c = count + 16;
     LPX_HIP_TRY(hipMalloc((void**)&g.d, sizeof(FusedParams) * c));
     LPX_HIP_TRY(hipMalloc((void**)&g.ds, sizeof(DevState) * c));
@@ -879,21 +890,25 @@ int fused_group_reserve(FusedGroupBuf& g, int count)
     LPX_HIP_TRY(hipHostMalloc((void**)&g.live_h, sizeof(int) * 2 * c));
     LPX_HIP_TRY(hipHostMalloc((void**)&g.fresh_h, sizeof(int) * c));
     LPX_HIP_TRY(hipHostMalloc((void**)&g.cur_h, sizeof(int) * c));
+    LPX_HIP_TRY(hipMalloc((void**)&g.comp_d, sizeof(int) * group_fused_comp_ints(c)));
+    LPX_HIP_TRY(hipHostMalloc((void**)&g.comp_h, sizeof(int) * 2 * (32 + c)));       // two windows' worth of {counts, list of parity 0}
+    LPX_HIP_TRY(hipMemsetAsync(g.comp_d, 0, sizeof(int) * group_fused_comp_ints(c), g.stream));
     g.cap = c;
     return 0;
 }
 
-// returns LPX_RESIDENT_RETRY when the group cannot take this path (nothing has been touched then)
-int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
-                    int* statuses, lpx_stats* stats, const DevState* inits, int min_active)
+FusedGroupBuf g_fgroups[3];          // [0], [1]: the two asynchronous batches (lpx_multi_run_begin / _end), [2]: the synchronous runs
+
+// parameter records, initial states and the init launch of a group; returns LPX_RESIDENT_RETRY when the group cannot take the
+// fused path (nothing has been touched then)
+int fused_prepare(FusedGroupBuf& g, lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
+                  const DevState* inits, int* per_node_out, int* batch_out, long long* budget_out)
 {
     static const bool enabled = [] { const char* e = std::getenv("LPX_GROUP_FUSED"); return !(e && e[0] == '0'); }();
     if (!enabled || count < 1) return LPX_RESIDENT_RETRY;
     for (int i = 0; i < count; ++i) if (ts[i]->fused_off) return LPX_RESIDENT_RETRY;
     for (int i = 0; i < count; ++i) if (!fused_buffers(ts[i])) return LPX_RESIDENT_RETRY;
-    FusedGroupBuf& g = g_fgroup;
     { int rc = fused_group_reserve(g, count); if (rc) return rc; }
-    const double t0 = now_ms();
     int per_node = 1, nfresh = 0, batch = 64;
     long long budget = 0;
     for (int k = 0; k < count; ++k) {
@@ -927,6 +942,46 @@ int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_
         LPX_HIP_TRY(hipMemcpyAsync(g.fresh_d, g.fresh_h, sizeof(int) * nfresh, hipMemcpyHostToDevice, g.stream));
         LPX_HIP_TRY(launch_group_fused_init(g.d, g.fresh_d, nfresh, g.ds, g.stream));
     }
+    *per_node_out = per_node; *batch_out = batch; *budget_out = budget;
+    return 0;
+}
+
+// what a run leaves on its handles and reports: latest records in g.hs / g.cur_h
+void fused_finish(FusedGroupBuf& g, lpx_tableau** ts, const int* dual, int count, bool unfinished_is_suspended, double ms, long long enq,
+                  int* statuses, lpx_stats* stats, double prof_ms, long long prof_n)
+{
+    for (int k = 0; k < count; ++k) {
+        lpx_tableau* t = ts[k];
+        const DevState& s = g.hs[k];
+        *t->hst = s;
+        const bool running = s.status == LPX_RUNNING;
+        statuses[k] = running ? (unfinished_is_suspended ? LPX_RUNNING : LPX_ITER_LIMIT) : s.status;
+        t->suspended = statuses[k] == LPX_RUNNING;
+        t->fsuspended = t->suspended;
+        t->frec_cur = g.cur_h[k];
+        // a finished node whose last pivot landed in the second buffer: the buffers trade places (every consumer -- solution
+        // read-back, parking, child assembly, download -- goes through t->T); an unfinished one keeps its pending pivot where it is
+        if (!running && s.pad[3] == 1) { std::swap(t->T, t->fT); drop_graph(t); }
+        if (stats) {
+            const double h2d = stats[k].h2d_ms, d2h = stats[k].d2h_ms;      // one-shot entry points keep their transfer times here
+            std::memset(&stats[k], 0, sizeof(lpx_stats));
+            stats[k].h2d_ms = h2d; stats[k].d2h_ms = d2h;
+            stats[k].pivots = s.iter; stats[k].fdf_pivots = s.fdf_count;
+            stats[k].cleanup_pivots = dual[k] ? s.primal_count : 0;
+            stats[k].loop_ms = ms / (double)count;
+            stats[k].launches = enq / (long long)count + 1;
+            if (k == 0) { stats[k].update_ms_sum = prof_ms; stats[k].update_launches = prof_n; }   // group-level figures
+        }
+    }
+}
+
+int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
+                    int* statuses, lpx_stats* stats, const DevState* inits, int min_active)
+{
+    FusedGroupBuf& g = g_fgroups[2];
+    const double t0 = now_ms();
+    int per_node = 1, batch = 64; long long budget = 0;
+    { const int rc = fused_prepare(g, ts, dual, count, popts, dopts, inits, &per_node, &batch, &budget); if (rc) return rc; }
     std::vector<int> live(count);
     for (int k = 0; k < count; ++k) live[k] = k;
     long long enq = 0; int window = 0; bool suspended_exit = false;
@@ -940,8 +995,16 @@ int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_
         size_t live_bytes = 0;
         for (size_t k = 0; k < live.size(); ++k) { lh[k] = live[k]; const lpx_tableau* t = ts[live[k]]; live_bytes += sizeof(double) * (size_t)t->R * t->ld; }
         LPX_HIP_TRY(hipMemcpyAsync(ld_, lh, sizeof(int) * live.size(), hipMemcpyHostToDevice, g.stream));
+        {   // the device's own live list starts the window equal to the host's (parity 0: windows are even)
+            const int hdr = group_fused_comp_hdr();
+            int* ch = g.comp_h + (window & 1) * (32 + g.cap);
+            std::memset(ch, 0, sizeof(int) * hdr);
+            ch[0] = (int)live.size();
+            for (size_t k = 0; k < live.size(); ++k) ch[hdr + k] = live[k];
+            LPX_HIP_TRY(hipMemcpyAsync(g.comp_d, ch, sizeof(int) * (hdr + live.size()), hipMemcpyHostToDevice, g.stream));
+        }
         for (int i = 0; i < batch; ++i)
-            LPX_HIP_TRY(launch_group_fused(g.d, ld_, (int)live.size(), per_node, (int)((enq + i) & 1), live_bytes, g.stream,
+            LPX_HIP_TRY(launch_group_fused(g.d, ld_, (int)live.size(), per_node, (int)((enq + i) & 1), live_bytes, g.stream, g.comp_d, g.cap,
                                            profile ? g.ev[2 * i] : nullptr, profile ? g.ev[2 * i + 1] : nullptr));
         enq += batch;
         LPX_HIP_TRY(launch_group_fused_gather(g.d, count, g.hs, g.cur_h, g.stream));
@@ -964,33 +1027,70 @@ int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_
         live.swap(next);
         if (!live.empty() && min_active > 0 && (int)live.size() <= min_active) { suspended_exit = true; break; }
     }
-    const double ms = now_ms() - t0;
-    for (int k = 0; k < count; ++k) {
-        lpx_tableau* t = ts[k];
-        const DevState& s = g.hs[k];
-        *t->hst = s;
-        const bool running = s.status == LPX_RUNNING;
-        statuses[k] = running ? (suspended_exit ? LPX_RUNNING : LPX_ITER_LIMIT) : s.status;
-        t->suspended = statuses[k] == LPX_RUNNING;
-        t->fsuspended = t->suspended;
-        t->frec_cur = g.cur_h[k];
-        // a finished node whose last pivot landed in the second buffer: the buffers trade places (every consumer -- solution
-        // read-back, parking, child assembly, download -- goes through t->T); an unfinished one keeps its pending pivot where it is
-        if (!running && s.pad[3] == 1) { std::swap(t->T, t->fT); drop_graph(t); }
-        if (stats) {
-            const double h2d = stats[k].h2d_ms, d2h = stats[k].d2h_ms;      // one-shot entry points keep their transfer times here
-            std::memset(&stats[k], 0, sizeof(lpx_stats));
-            stats[k].h2d_ms = h2d; stats[k].d2h_ms = d2h;
-            stats[k].pivots = s.iter; stats[k].fdf_pivots = s.fdf_count;
-            stats[k].cleanup_pivots = dual[k] ? s.primal_count : 0;
-            stats[k].loop_ms = ms / (double)count;
-            stats[k].launches = enq / (long long)count + 1;
-            if (k == 0) { stats[k].update_ms_sum = prof_ms; stats[k].update_launches = prof_n; }   // group-level figures
-        }
-    }
+    fused_finish(g, ts, dual, count, suspended_exit, now_ms() - t0, enq, statuses, stats, prof_ms, prof_n);
     return 0;
 }
 
+// ---- the same in two halves: one window of `steps` pivots of every run of a batch, enqueued and collected separately, so that the
+//      host can work on one batch (read-back, parking, assembly of the next nodes) while the other one pivots ----
+struct FusedAsync { bool active = false; std::vector<lpx_tableau*> ts; std::vector<int> dual; double t0 = 0; long long enq = 0; };
+FusedAsync g_fasync[2];
+
+}  // namespace
+
+extern "C" {
+
+int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts, int steps)
+{
+    if (slot < 0 || slot > 1 || !ts || !dual || count < 1 || steps < 1) { set_error("lpx_multi_run_begin: bad argument"); return LPX_EINVAL; }
+    FusedAsync& a = g_fasync[slot];
+    if (a.active) { set_error("lpx_multi_run_begin: this slot has a batch in flight (lpx_multi_run_end first)"); return LPX_EINVAL; }
+    lpx_run_opts pd, dd;
+    if (!popts) { lpx_default_opts(&pd, 0); popts = &pd; }
+    if (!dopts) { lpx_default_opts(&dd, 1); dopts = &dd; }
+    for (int i = 0; i < count; ++i) {
+        if (!ts[i] || ts[i]->R < 2) { set_error("lpx_multi_run_begin: null or empty tableau"); return LPX_EINVAL; }
+        if (ts[i]->suspended2) { set_error("lpx_multi_run_begin: a run suspended on the two-launch kernels cannot continue here"); return LPX_EINVAL; }
+    }
+    if (popts->profile || dopts->profile) return 1;
+    FusedGroupBuf& g = g_fgroups[slot];
+    int per_node = 1, batch = 64; long long budget = 0;
+    const double t0 = now_ms();
+    {
+        const int rc = fused_prepare(g, ts, dual, count, popts, dopts, nullptr, &per_node, &batch, &budget);
+        if (rc == LPX_RESIDENT_RETRY) return 1;                 // not available for this batch: the caller takes lpx_multi_run_some
+        if (rc) return rc;
+    }
+    steps = (steps + 1) & ~1;
+    size_t live_bytes = 0;
+    for (int k = 0; k < count; ++k) { g.live_h[k] = k; live_bytes += sizeof(double) * (size_t)ts[k]->R * ts[k]->ld; }
+    LPX_HIP_TRY(hipMemcpyAsync(g.live_d, g.live_h, sizeof(int) * count, hipMemcpyHostToDevice, g.stream));
+    { const int hdr = group_fused_comp_hdr();
+      std::memset(g.comp_h, 0, sizeof(int) * hdr);
+      g.comp_h[0] = count;
+      for (int k = 0; k < count; ++k) g.comp_h[hdr + k] = k;
+      LPX_HIP_TRY(hipMemcpyAsync(g.comp_d, g.comp_h, sizeof(int) * (hdr + count), hipMemcpyHostToDevice, g.stream)); }
+    for (int i = 0; i < steps; ++i) LPX_HIP_TRY(launch_group_fused(g.d, g.live_d, count, per_node, i & 1, live_bytes, g.stream, g.comp_d, g.cap));
+    LPX_HIP_TRY(launch_group_fused_gather(g.d, count, g.hs, g.cur_h, g.stream));
+    a.active = true; a.ts.assign(ts, ts + count); a.dual.assign(dual, dual + count); a.t0 = t0; a.enq = steps;
+    return 0;
+}
+
+int lpx_multi_run_end(int slot, int* statuses, lpx_stats* stats)
+{
+    if (slot < 0 || slot > 1 || !statuses) { set_error("lpx_multi_run_end: bad argument"); return LPX_EINVAL; }
+    FusedAsync& a = g_fasync[slot];
+    if (!a.active) { set_error("lpx_multi_run_end: no batch in flight in this slot"); return LPX_EINVAL; }
+    FusedGroupBuf& g = g_fgroups[slot];
+    a.active = false;
+    LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+    fused_finish(g, a.ts.data(), a.dual.data(), (int)a.ts.size(), true, now_ms() - a.t0, a.enq, statuses, stats, 0.0, 0);
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
 }  // namespace
 
 static int multi_run_batched(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts,
@@ -1622,6 +1722,12 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
         }
     }
     static const bool batched_env = [] { const char* e = std::getenv("LPX_BATCHED"); return !(e && e[0] == '0'); }();
+    if (batched_env && count >= 1 && (popts->profile || dopts->profile)) {
+        // profile mode: the fused group launch bracketed by HIP events (stats[0].update_ms_sum / update_launches are the group's)
+        bool ok = true;
+        for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2) ok = false;
+        if (ok) { const int rc = multi_run_fused(ts, dual, count, popts, dopts, statuses, stats, nullptr, 0); if (rc != LPX_RESIDENT_RETRY) return rc; }
+    }
     if (batched_env && count >= 2 && !popts->profile && !dopts->profile) {
         bool ok = true;
         for (int i = 0; i < count; ++i) if (!ts[i] || ts[i]->R < 2 || (!dual[i] && !ts[i]->us)) ok = false;
