@@ -596,6 +596,22 @@ def main():
             rv = L.DeviceRevised(A3, -c3, b3)
             st3, s3 = rv.run(max_iter=args.revised_iters, batch=50)
             rho3 = rv.residual()
+            # per-kernel durations (HIP events bound to each dispatch, eager launches) over the NEXT 200 real iterations: SURVEY 8d asks
+            # for per-kernel achieved GB/s, never a fused total against the unfused byte count
+            kp = rv.profile(200)
+            pmc3, pmc3_src = committed_profile("pmc_traffic.json")
+
+            def rv_kernel(name, us, alg_bytes):
+                tr = None
+                if pmc3:
+                    hit = [v for k_, v in pmc3.items() if k_.startswith(f"lpx::{name}<") or k_.startswith(f"void lpx::{name}<") or f"::{name}<" in k_]
+                    if hit:
+                        tr = max(hit, key=lambda v: v.get("launches_fetch", 0))["hbm_bytes_per_launch"]
+                ach = alg_bytes / (us * 1e-6) / 1e9 if us > 0 else None
+                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": tr, "traffic_source": pmc3_src if tr else None,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": us, "launches": kp["iterations"],
+                        "timing": "HIP start/stop events bound to each dispatch on the library stream, this run"}
             rv.set_refactor_mode(1)
             rv.refactor()                                   # fast form once for its allocations
             rv.run(max_iter=args.revised_iters, batch=50)   # drift the inverse again (same iterations: the count restarts)
@@ -617,6 +633,15 @@ def main():
                               "engine_bytes_per_iteration": 8.0 * 4096 * 8192 + 16.0 * 4097 * 4097,
                               "engine_dataflow": "rv_price (A^T read once, nt) + rv_pick + rv_upd_ftran (W read+written once: the previous "
                                                  "pivot's rank-1 update fused with d = B^-1 a_q) + rv_select2; 4 launches per iteration",
+                              "kernels": {
+                                  "rv_price": rv_kernel("rv_price", kp["rv_price"], 8.0 * 4096 * 8192),
+                                  "rv_upd_ftran": dict(rv_kernel("rv_upd_ftran", kp["rv_upd_ftran"], 16.0 * 4096 * 4096),
+                                                       note="W (134 MB) is at home in the Infinity Cache: part of this rate is cache residency"),
+                                  "rv_pick": {"bound": "latency (one workgroup: reduces the 2048 pricing candidates, copies the entering column)",
+                                              "avg_kernel_us": kp["rv_pick"]},
+                                  "rv_select2": {"bound": "latency (one workgroup: ratio test with the 1e-12 hysteresis, pivot row, (pi, z) row, bookkeeping)",
+                                                 "avg_kernel_us": kp["rv_select2"]},
+                                  "sum_us": kp["rv_price"] + kp["rv_pick"] + kp["rv_upd_ftran"] + kp["rv_select2"]},
                               "drift": {"policy": "residual check every 256 iterations, refactor above 1e-9 (default)",
                                         "residual_after_run": rho3[0], "residual_after_fast_refactor": rho3b[0]},
                               "refactor_exact_s": refac_s,

@@ -263,15 +263,21 @@ int  lpx_revised_set_refactor(lpx_revised* r, int every);
  * |B^-1 B - I| <= 1e-9) and falls back to mode 0 by itself when the maintained inverse is too far off to contract. */
 int  lpx_revised_set_refactor_mode(lpx_revised* r, int mode);
 /* Drift control of the product-form inverse (the reference never drifts: it re-inverts every iteration).  Every
- * `check_every` iterations lpx_revised_run evaluates rho = max_i |(B x_B)_i - b_i| / (1 + max_i |b_i|) on the device (one
- * m x m sweep) and refactorises when rho > tol.  Default: check_every = 256, tol = 1e-9; check_every = 0 switches it off.
+ * `check_every` iterations lpx_revised_run evaluates two residuals on the device -- rho = max_i |(B x_B)_i - b_i| / (1 + max_i |b_i|)
+ * and, for a fixed probe vector v of order one, rho2 = max_i |(B^-1 (B v))_i - v_i| / (1 + max|v|), which sees an error of B^-1 in
+ * directions b does not excite (three m x m sweeps in all) -- and refactorises when max(rho, rho2) > tol.  Default: check_every = 256, tol = 1e-9; check_every = 0 switches it off.
  * lpx_revised_set_refactor(r, k > 0) replaces it by an unconditional refactorisation every k iterations. */
 int  lpx_revised_set_drift_policy(lpx_revised* r, int check_every, double tol);
-int  lpx_revised_residual(lpx_revised* r, double* rel /* rho */, double* abs_ /* max_i |(B x_B)_i - b_i| */);
+int  lpx_revised_residual(lpx_revised* r, double* rel /* max(rho, rho2) */, double* abs_ /* max_i |(B x_B)_i - b_i| */);
 /* Counters since creation; gemm_ms / gemm_calls: HIP-event time and number of the matrix-core contractions (2 m^3 flop each)
  * of the LAST fast refactorisation.  Any pointer may be NULL. */
 int  lpx_revised_refactor_stats(lpx_revised* r, int* refactors, int* fast_steps, int* fast_fallbacks, double* last_residual,
                                 double* gemm_ms, int* gemm_calls);
+/* Measurement: mean HIP-event duration [us] of each kernel of the engine's four-launch iteration -- us[0] rv_price (r_N = c_N - pi N,
+ * MultiplyRow + Subtract :71-72), us[1] rv_pick (entering candidate :76-83, column copy :95), us[2] rv_upd_ftran (d = B^-1 a_q, Multiply
+ * :96, fused with the previous pivot's update of [[B^-1, x_B]]), us[3] rv_select2 (ratio test :99-112, bookkeeping :121-124) -- over up to
+ * `iters` real iterations from the handle's current basis; *measured = iterations that completed a pivot. */
+int  lpx_revised_profile(lpx_revised* r, int iters, double* us /* [4] */, int* measured);
 /* Invert (Models/RevisedPrimalSimplex.cs:402-456), bit for bit: Gauss-Jordan with partial pivoting on
  * [M | I]; M and inv are n x n row-major host buffers.  Returns 0 or LPX_E_SINGULAR (:426). */
 int  lpx_invert(const double* M, int n, double* inv);

@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
     L.lpx_sensitivity_apply_change.argtypes = _sens + [C.c_char_p, C.c_double, ip, ip, C.c_char_p, C.c_int]
     L.lpx_sensitivity_shadow_prices.argtypes = _sens + [C.c_char_p, C.c_int]
     L.lpx_sensitivity_solve_duality.argtypes = _sens + [C.POINTER(SolveOpts), C.POINTER(Result)]
+    L.lpx_revised_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int)]
     L.lpx_revised_refactor.argtypes = [vp]
     L.lpx_revised_set_refactor_mode.argtypes = [vp, C.c_int]
     L.lpx_revised_set_drift_policy.argtypes = [vp, C.c_int, C.c_double]

@@ -758,6 +758,25 @@ void publish_best(Ctx& c, Exchange& ex, int nvars)
     c.best_x = xs;
 }
 
+// The replicated warm-up relies on every rank computing the SAME frontier (same LPs, same arithmetic, same decisions).  If that ever
+// fails -- round 2's record scale7: a kernel whose result depended on workgroup scheduling under GPU sharing gave the ranks different
+// root LPs; they left the replicated phase on different levels and then sat in collectives that no longer matched until the job was
+// killed -- the ranks must find out instead of waiting for good: a fingerprint of the frontier as it stands when the replicated
+// phase ends (hand-out, or the search running dry / out of budget before it) travels as {+h, -h} in the first all-reduce of every
+// rank; max(+h) == -max(-h) iff all ranks agree.  Every rank of a sharded search issues that first all-reduce, also one whose search
+// ended while replicated.  52 bits: exact in a double.
+template <class FN> double frontier_fingerprint(const std::vector<FN>& frontier, bool handed_out)
+{
+    uint64_t h = 1469598103934665603ull ^ (handed_out ? 0x9e3779b97f4a7c15ull : 0ull);
+    auto mix = [&](uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); };
+    mix((uint64_t)frontier.size());
+    for (const FN& f : frontier) {
+        mix((uint64_t)f.cuts.size());
+        for (const Cut& k : f.cuts) { mix((uint64_t)(uint32_t)k.var); mix((uint64_t)(int)k.rel); int64_t b; double d = k.bound; std::memcpy(&b, &d, sizeof(b)); mix((uint64_t)b); }
+    }
+    return (double)(h & ((1ull << 52) - 1));
+}
+
 void LevelSearch(Ctx& c)
 {
     const int world = std::max(1, c.opt.world), rank = c.opt.rank;
@@ -772,9 +791,12 @@ void LevelSearch(Ctx& c)
     c.count_work = !(replicated && rank != 0);
     c.budget_used = 0; c.budget_cap = c.opt.max_nodes;
     bool failed = false; std::string fail_msg; int fail_code = 0;
+    double agree_h = -1.0; bool agree_sent = !sharded;      // fingerprint of the end of the replicated phase, sent once
+    if (sharded && !replicated) agree_h = frontier_fingerprint(frontier, false);       // a world of one (LPX_COMM_SHARD_ONE): nothing was replicated
     for (;;) {
         if (replicated && frontier.size() >= want) {
             // hand the replicated frontier out: node i -> rank i % world, subtrees stay local from here on
+            agree_h = frontier_fingerprint(frontier, true);
             std::vector<FNode> mine;
             for (size_t i = 0; i < frontier.size(); ++i) if ((int)(i % world) == rank) mine.push_back(std::move(frontier[i]));
             frontier.swap(mine);
@@ -830,13 +852,20 @@ void LevelSearch(Ctx& c)
         frontier.swap(next);
         for (FNode& f : parked) frontier.push_back(std::move(f));
         if (c.stop) frontier.clear();
-        if (!sharded || replicated) {
+        if (!sharded) {
             if (frontier.empty() || c.stop) break;
             continue;
         }
+        if (replicated) {
+            if (!(frontier.empty() || c.stop)) continue;
+            // the search ended inside the replicated warm-up: the same on every rank if all is well -- one all-reduce says so
+            agree_h = frontier_fingerprint(frontier, false);
+            replicated = false;
+        }
         // ---- X1: ONE all-reduce(max) per level: incumbent bound, "someone still has work", "someone failed", the deepest
-        //      pooled node, and every rank's pool size (slot r; -1 = this rank takes no more nodes) for the rebalancing below
-        std::vector<double> vals(4 + (size_t)world, -INFINITY);
+        //      pooled node, and every rank's pool size (slot r; -1 = this rank takes no more nodes) for the rebalancing below;
+        //      in a rank's FIRST one also the fingerprint of its replicated phase as {+h, -h}
+        std::vector<double> vals(6 + (size_t)world, -INFINITY);
         int maxd = 0; for (const FNode& f : frontier) maxd = std::max(maxd, f.depth);
         vals[0] = c.has_best ? c.best : -INFINITY;
         vals[1] = frontier.empty() ? 0.0 : 1.0;
@@ -844,8 +873,16 @@ void LevelSearch(Ctx& c)
         vals[3] = (double)maxd;
         // a rank whose share of the budget is used up takes no more nodes either: what it received would be dropped at the next level
         vals[4 + rank] = (c.stop || c.over_budget()) ? -1.0 : (double)frontier.size();
+        const bool first = !agree_sent;
+        if (first && !failed) { vals[4 + world] = agree_h; vals[5 + world] = -agree_h; }
+        agree_sent = true;
         const double mine = vals[0];
         ex.max(vals.data(), (int)vals.size());
+        if (first && vals[2] <= 0.0 && vals[4 + world] != -vals[5 + world]) {
+            failed = true; fail_code = LPX_EDEVICE; c.stop = true;
+            fail_msg = "sharded search: the replicated warm-up ended differently on different ranks (the node LPs must be bit-identical across ranks)";
+            break;
+        }
         if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
         if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
         if (vals[1] == 0.0) break;
@@ -952,16 +989,19 @@ void WarmSearch(Ctx& c)
             int fl = 0, ce = 0;
             const std::vector<Cut> none;
             int k = decide(c, none, lp, 0, "Root Problem", fl, ce);
-            if (k < 0) { if (lp.kslot >= 0) lpx_store_release(lp.kstore, lp.kslot); return; }   // the same on every rank: nobody waits
-            add_children(frontier, none, 0, lp, k, fl, ce);
+            if (k < 0) { if (lp.kslot >= 0) lpx_store_release(lp.kstore, lp.kslot); if (!sharded) return; }   // sharded: on to the one all-reduce that says every rank ended here
+            else add_children(frontier, none, 0, lp, k, fl, ce);
         } catch (const LpxException& e) {
             // the peers solve the same root and go on to their first level's all-reduce: meet them there (as LevelSearch does)
             if (!sharded) throw;
             failed = true; fail_msg = e.what(); fail_code = e.code; c.stop = true; replicated = false; frontier.clear();
         }
     }
+    double agree_h = -1.0; bool agree_sent = !sharded;      // fingerprint of the end of the replicated phase (see frontier_fingerprint), sent once
+    if (sharded && !replicated && !failed) agree_h = frontier_fingerprint(frontier, false);
     for (;;) {
         if (replicated && frontier.size() >= want) {
+            agree_h = frontier_fingerprint(frontier, true);
             std::vector<WNode> mine;
             for (size_t i = 0; i < frontier.size(); ++i) {
                 if ((int)(i % world) == rank) mine.push_back(std::move(frontier[i]));
@@ -1025,13 +1065,25 @@ void WarmSearch(Ctx& c)
         frontier.swap(next);
         for (WNode& f : parked) frontier.push_back(std::move(f));
         c.levels++;
-        // X1: incumbent, "someone still has work", "someone failed"
-        double vals[3] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0, failed ? 1.0 : 0.0};
+        if (replicated && sharded && (frontier.empty() || c.stop)) {     // ended inside the replicated warm-up: one all-reduce says every rank did
+            agree_h = frontier_fingerprint(frontier, false);
+            replicated = false;
+        }
+        // X1: incumbent, "someone still has work", "someone failed"; in a rank's first one also the fingerprint {+h, -h} of its replicated phase
+        double vals[5] = {c.has_best ? c.best : -INFINITY, (frontier.empty() || c.stop) ? 0.0 : 1.0, failed ? 1.0 : 0.0, -INFINITY, -INFINITY};
         if (!replicated && sharded) {
+            const bool first = !agree_sent;
+            if (first && !failed) { vals[3] = agree_h; vals[4] = -agree_h; }
+            agree_sent = true;
             const double mine = vals[0];
-            ex.max(vals, 3);
+            ex.max(vals, 5);
             if (vals[0] > mine) { if (!(c.has_best && c.best >= vals[0])) { c.best = vals[0]; c.has_best = true; c.best_x.clear(); c.best_key.clear(); } }
             if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
+            if (first && vals[3] != -vals[4]) {
+                failed = true; fail_code = LPX_EDEVICE; c.stop = true;
+                fail_msg = "sharded search: the replicated warm-up ended differently on different ranks (the node LPs must be bit-identical across ranks)";
+                break;
+            }
         }
         if (vals[1] == 0.0) break;
     }

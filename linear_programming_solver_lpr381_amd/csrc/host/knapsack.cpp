@@ -394,8 +394,21 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
     const bool sharded = (world > 1 || opt.shard_one) && (bool)opt.allreduce_max;
     const int round = 256;
     bool failed = false; std::string fail_msg; int fail_code = 0;
+    // fingerprint of the heap as the replicated warm-up leaves it: {+h, -h} in every rank's FIRST all-reduce, max(+h) == -max(-h) iff
+    // all ranks agree -- ranks that do not (a device path whose result depends on scheduling, as in round 2's record scale7) return an
+    // error instead of waiting in collectives that no longer match (the same device as csrc/host/bnb.cpp frontier_fingerprint)
+    auto fingerprint = [&](bool handed_out) {
+        uint64_t h = 1469598103934665603ull ^ (handed_out ? 0x9e3779b97f4a7c15ull : 0ull);
+        auto mix = [&](uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); };
+        mix((uint64_t)pq.d.size()); mix((uint64_t)S.popped);
+        for (const auto& e : pq.d) { int64_t b; double d = e.n->bound; std::memcpy(&b, &d, sizeof(b)); mix((uint64_t)b); mix((uint64_t)(uint32_t)e.n->item); mix((uint64_t)(uint32_t)e.n->depth); }
+        return (double)(h & ((1ull << 52) - 1));
+    };
+    double agree_h = -1.0; bool agree_sent = !sharded;
+    if (sharded && !replicated) agree_h = fingerprint(false);
     for (;;) {
         if (replicated && pq.d.size() >= (size_t)(4 * world)) {
+            agree_h = fingerprint(true);
             Heap mine;
             for (size_t i = 0; i < pq.d.size(); ++i) if ((int)(i % world) == rank) mine.push(pq.d[i].n);
             pq.d.swap(mine.d);
@@ -416,12 +429,24 @@ SimplexResult BranchAndBoundKnapsack::Solve(const LPProblem& problem, UpdatePivo
             if (!sharded) throw;
             failed = true; fail_msg = e.what(); fail_code = e.code; more = false; replicated = false;
         }
+        if (sharded && replicated && (!more || pq.d.empty())) {             // ended inside the replicated warm-up: one all-reduce says every rank did
+            agree_h = fingerprint(false);
+            replicated = false;
+        }
         if (sharded && !replicated) {
-            double vals[3] = {S.has_best ? S.best : -INFINITY, (more && !pq.d.empty()) ? 1.0 : 0.0, failed ? 1.0 : 0.0};
+            double vals[5] = {S.has_best ? S.best : -INFINITY, (more && !pq.d.empty()) ? 1.0 : 0.0, failed ? 1.0 : 0.0, -INFINITY, -INFINITY};
+            const bool first = !agree_sent;
+            if (first && !failed) { vals[3] = agree_h; vals[4] = -agree_h; }
+            agree_sent = true;
             const double mine = vals[0];
-            opt.allreduce_max(vals, 3);                                     // X1: incumbent + termination (+ "someone failed")
+            opt.allreduce_max(vals, 5);                                     // X1: incumbent + termination (+ "someone failed", + the fingerprint once)
             if (vals[0] > mine) { S.best = vals[0]; S.has_best = true; std::fill(S.bestX.begin(), S.bestX.end(), -1); }
             if (vals[2] > 0.0) { if (!failed) { failed = true; fail_code = LPX_EDEVICE; fail_msg = "sharded search: a peer rank failed"; } break; }
+            if (first && vals[3] != -vals[4]) {
+                failed = true; fail_code = LPX_EDEVICE;
+                fail_msg = "sharded search: the replicated warm-up ended differently on different ranks (the bounds must be bit-identical across ranks)";
+                break;
+            }
             if (vals[1] == 0.0) break;
         } else if (!more || pq.d.empty()) {
             if (cap_nodes > 0 && S.popped >= cap_nodes) break;

@@ -150,6 +150,11 @@ hipError_t launch_resident_primal_col(double* T, int ld, int R, int C, int grid,
                                       double eps, double tol, int max_iter, int chunk, hipStream_t s);
 
 void set_error(const std::string& msg);
+// Device memory the library keeps for reuse after its owner is gone (the chunk cache of destroyed parent stores, lpx_tableau.cpp):
+// trim_device_caches() gives all of it back; malloc_retry() is hipMalloc that does so and tries once more before it reports
+// hipErrorOutOfMemory -- every large allocation of the library goes through it.
+void trim_device_caches();
+hipError_t malloc_retry(void** p, size_t bytes);
 int ensure_device();                // binds a device and sets kernel attributes once
 double now_ms();
 // hipStreamCreate costs 4-9 ms on this stack (an HSA queue each) while the hardware runs a handful of queues anyway:

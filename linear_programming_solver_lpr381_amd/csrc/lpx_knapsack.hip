@@ -600,7 +600,7 @@ int lpx_knapsack_create(const double* profit, const double* weight, int n, doubl
     hipError_t e = hipSuccess;
     auto up = [&](void** d, const void* h, size_t bytes) {
         if (e != hipSuccess) return;
-        e = hipMalloc(d, bytes);
+        e = malloc_retry(d, bytes);
         if (e == hipSuccess) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
     };
     up((void**)&k->ws, ws.data(), sizeof(double) * n); up((void**)&k->ps, ps.data(), sizeof(double) * n);
@@ -733,7 +733,7 @@ int lpx_knapsack_expand_begin(lpx_knapsack* k, int count, const int64_t* parent,
         if (need > KN_CHUNK_WORDS) { set_error("lpx_knapsack_expand_batch: node deeper than a store chunk"); return LPX_EINVAL; }
         if (k->chunks.empty() || k->chunk_used + need > KN_CHUNK_WORDS) {
             uint32_t* c = nullptr;
-            if (hipMalloc((void**)&c, sizeof(uint32_t) * KN_CHUNK_WORDS) != hipSuccess) { set_error("lpx_knapsack_expand_batch: out of device memory for the node store"); return LPX_ENOMEM; }
+            if (malloc_retry((void**)&c, sizeof(uint32_t) * KN_CHUNK_WORDS) != hipSuccess) { set_error("lpx_knapsack_expand_batch: out of device memory for the node store"); return LPX_ENOMEM; }
             k->chunks.push_back(c); k->chunk_used = 0;
         }
         *out = k->chunks.back() + k->chunk_used;

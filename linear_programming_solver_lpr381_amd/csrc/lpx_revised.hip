@@ -12,6 +12,7 @@
 //                   (Models/RevisedPrimalSimplex.cs:123-124) preserves relative order, so "first in
 //                   list order" == smallest key with keys handed out increasingly.
 #include "lpx_block.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -597,6 +598,10 @@ __global__ __launch_bounds__(256) void rv_refill_pi(RvParams P, const double* __
 // B x_B = sum_k x_B[k] * column Bidx[k] of [A | I]; columns are rows of A^T, so thread i of a workgroup reads A^T[col][i]
 // coalesced; the k range is split over blockIdx.y and the slices meet in a [KS][m] buffer (fixed order: deterministic).
 static constexpr int RVR_KS = 32;
+// probe vector of the second check (below): fixed, of order one, no zeros
+__device__ __forceinline__ double rv_probe_v(int k) { return 0.75 + (double)((unsigned)k * 2654435761u >> 22) * (1.0 / 2048.0); }
+// PROBE = false: y = B x_B;  true: y = B v with the probe vector v
+template <bool PROBE>
 __global__ __launch_bounds__(256) void rv_resid_partial(RvParams P, double* __restrict__ part)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(256) void rv_resid_partial(RvParams P, double* __re
     double acc = 0.0;
     for (int k = k0; k < k1; ++k) {
         const int col = P.Bidx[k];
-        const double xk = P.W[(size_t)k * P.ldw + P.m];
+        const double xk = PROBE ? rv_probe_v(k) : P.W[(size_t)k * P.ldw + P.m];
         if (i < P.m) acc += (col < P.n) ? P.AT[(size_t)col * P.ldat + i] * xk : ((i == col - P.n) ? xk : 0.0);
     }
     if (i < P.m) part[(size_t)blockIdx.y * P.m + i] = acc;
@@ -627,6 +632,37 @@ __global__ __launch_bounds__(1024) void rv_resid_final(RvParams P, const double*
         for (int k = 1; k < 16; ++k) { e = fmax(e, s_a[k]); bm = fmax(bm, s_b[k]); }
         out[0] = e / (1.0 + bm); out[1] = e;
     }
+}
+
+// Second probe (advisor finding r02: the residual above sees B^-1 only through b): w = B^-1 (B v) for a fixed probe vector v must
+// give v back; rho2 = max_i |w_i - v_i| / (1 + max_i |v_i|) sees an error of the maintained inverse in a direction b does not
+// excite.  y = B v comes from rv_resid_partial<true> (slices summed here, fixed order), w_i = W[i, 0..m) . y is one wave per row.
+__global__ __launch_bounds__(256) void rv_probe_sum(RvParams P, const double* __restrict__ part, double* __restrict__ y)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.m) return;
+    double s = 0.0;
+    for (int k = 0; k < RVR_KS; ++k) s += part[(size_t)k * P.m + i];
+    y[i] = s;
+}
+__global__ __launch_bounds__(256) void rv_probe_rows(RvParams P, const double* __restrict__ y, double* __restrict__ err)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= P.m) return;
+    const double s = wave_dot(P.W + (size_t)i * P.ldw, y, P.m, lane);
+    if (lane == 0) err[i] = fabs(s - rv_probe_v(i));
+}
+__global__ __launch_bounds__(1024) void rv_probe_final(RvParams P, const double* __restrict__ err, double* out)
+{
+    __shared__ double s_a[16];
+    double e = 0.0;
+    for (int i = threadIdx.x; i < P.m; i += 1024) e = fmax(e, err[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) e = fmax(e, __shfl_xor(e, d, 64));
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int k = 1; k < 16; ++k) e = fmax(e, s_a[k]); out[2] = e / (1.0 + 1.75); }     // |v_i| < 1.75
 }
 
 // fast refactorisation (Newton-Schulz on the matrix cores, lpx_mfma.hip): x_B = B^-1 b and (pi, z) = c_B [B^-1, x_B] from W in place
@@ -743,7 +779,7 @@ struct lpx_revised {
     double* part_v = nullptr; int32_t* part_k = nullptr; int32_t* part_c = nullptr;   // candidates of rv_price
     int refactor_mode = 0;          // 0 = exact Gauss-Jordan (the reference's Invert, bit for bit), 1 = Newton-Schulz on the matrix cores
     int drift_every = 256; double drift_tol = 1e-9;    // residual check of the maintained inverse (0 = off)
-    double last_residual = -1.0; int refactors = 0, fast_steps = 0, fast_fallbacks = 0;
+    double last_residual = -1.0, last_probe = -1.0; int refactors = 0, fast_steps = 0, fast_fallbacks = 0;
     double gemm_ms = 0.0; int gemm_calls = 0;       // HIP-event time of the matrix-core contractions of the last fast refactorisation
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *nsR = nullptr, *nsX = nullptr, *scratch = nullptr; unsigned long long* nsmax = nullptr; double* resid = nullptr;
@@ -775,6 +811,15 @@ template <int PER> static void rv_launch_fused(const RvParams& p, hipStream_t s)
     hipLaunchKernelGGL(rv_pick, dim3(1), dim3(RV_NT), 0, s, p);
     hipLaunchKernelGGL(rv_upd_ftran<PER>, dim3(std::min(p.m, 4 * RVF_GRID)), dim3(RVF_NT), 0, s, p);
     hipLaunchKernelGGL(rv_select2, dim3(1), dim3(SEL_NT), 0, s, p);
+}
+
+// the same with every kernel bracketed by its own pair of HIP events (bound to the dispatch): ev[0..7] = {price, pick, upd_ftran, select2}
+template <int PER> static void rv_launch_fused_profiled(const RvParams& p, hipStream_t s, hipEvent_t* ev)
+{
+    hipExtLaunchKernelGGL(rv_price<PER>, dim3(p.nblk), dim3(RVF_NT), 0, s, ev[0], ev[1], 0, p);
+    hipExtLaunchKernelGGL(rv_pick, dim3(1), dim3(RV_NT), 0, s, ev[2], ev[3], 0, p);
+    hipExtLaunchKernelGGL(rv_upd_ftran<PER>, dim3(std::min(p.m, 4 * RVF_GRID)), dim3(RVF_NT), 0, s, ev[4], ev[5], 0, p);
+    hipExtLaunchKernelGGL(rv_select2, dim3(1), dim3(SEL_NT), 0, s, ev[6], ev[7], 0, p);
 }
 
 // applies the pending W update, if there is one (fused path); stream-ordered, then waits
@@ -843,7 +888,7 @@ int lpx_revised_create(int m, int n, const double* A, const double* c, const dou
     const size_t wb = sizeof(double) * (size_t)(m + 1) * r->ldw;
     double* Atmp = nullptr;
 #define RALLOC(ptr, bytes)                                                              \
-    do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                            \
+    do { hipError_t e_ = malloc_retry((void**)&(ptr), (bytes));                            \
          if (e_ != hipSuccess) { set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_)); \
              hipFree(Atmp); lpx_revised_destroy(r); return e_ == hipErrorOutOfMemory ? LPX_ENOMEM : LPX_EDEVICE; } } while (0)
     RALLOC(r->AT, atb); RALLOC(r->c, sizeof(double) * n); RALLOC(r->W, wb);
@@ -1018,17 +1063,24 @@ int lpx_revised_residual(lpx_revised* r, double* rel, double* abs_)
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
     { const int rc = rv_flush_pending(r); if (rc) return rc; }
     const int m = r->m;
-    if (!r->resid) LPX_HIP_TRY(hipMalloc((void**)&r->resid, sizeof(double) * ((size_t)RVR_KS * m + 2)));
+    // layout of r->resid: [0] rho, [1] abs, [2] rho2, [3] pad, [4 ..) the [KS][m] slices, then y[m], then err[m]
+    if (!r->resid) LPX_HIP_TRY(hipMalloc((void**)&r->resid, sizeof(double) * ((size_t)(RVR_KS + 2) * m + 4)));
     lpx_run_opts od; lpx_default_opts(&od, 1);
     RvParams p = rv_params(r, &od);
-    hipLaunchKernelGGL(rv_resid_partial, dim3((m + 255) / 256, RVR_KS), dim3(256), 0, r->stream, p, r->resid + 2);
-    hipLaunchKernelGGL(rv_resid_final, dim3(1), dim3(1024), 0, r->stream, p, (const double*)(r->resid + 2), (const double*)r->b, r->resid);
+    double* part = r->resid + 4; double* y = part + (size_t)RVR_KS * m; double* err = y + m;
+    hipLaunchKernelGGL(rv_resid_partial<false>, dim3((m + 255) / 256, RVR_KS), dim3(256), 0, r->stream, p, part);
+    hipLaunchKernelGGL(rv_resid_final, dim3(1), dim3(1024), 0, r->stream, p, (const double*)part, (const double*)r->b, r->resid);
+    hipLaunchKernelGGL(rv_resid_partial<true>, dim3((m + 255) / 256, RVR_KS), dim3(256), 0, r->stream, p, part);
+    hipLaunchKernelGGL(rv_probe_sum, dim3((m + 255) / 256), dim3(256), 0, r->stream, p, (const double*)part, y);
+    hipLaunchKernelGGL(rv_probe_rows, dim3((m + 3) / 4), dim3(256), 0, r->stream, p, (const double*)y, err);
+    hipLaunchKernelGGL(rv_probe_final, dim3(1), dim3(1024), 0, r->stream, p, (const double*)err, r->resid);
     LPX_HIP_TRY(hipGetLastError());
-    double out[2] = {0, 0};
+    double out[3] = {0, 0, 0};
     LPX_HIP_TRY(hipMemcpyAsync(out, r->resid, sizeof(out), hipMemcpyDeviceToHost, r->stream));
     LPX_HIP_TRY(hipStreamSynchronize(r->stream));
-    r->last_residual = out[0];
-    if (rel) *rel = out[0];
+    r->last_residual = out[0] > out[2] ? out[0] : out[2];      // the larger of the two probes drives the drift policy
+    r->last_probe = out[2];
+    if (rel) *rel = r->last_residual;
     if (abs_) *abs_ = out[1];
     return 0;
 }
@@ -1115,6 +1167,60 @@ static int revised_run_segment(lpx_revised* r, const lpx_run_opts* o, lpx_pivot_
     LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
     init.pad[0] = r->hst->pad[0] > 0 ? r->hst->pad[0] : r->n;
     return run_device_loop(c, init, o, (long long)o->max_iter + 2, cb, user, st);
+}
+
+// Per-kernel durations of the four-launch iteration ("report per-kernel achieved GB/s"): runs up to `iters` iterations
+// from the handle's current basis eagerly, every kernel between its own HIP events; us[4] = mean microseconds of rv_price, rv_pick,
+// rv_upd_ftran, rv_select2 over the iterations that completed a pivot.  The iterations are real ones (the basis moves on).
+int lpx_revised_profile(lpx_revised* r, int iters, double* us, int* measured)
+{
+    if (!r || !us || iters < 1) { set_error("lpx_revised_profile: bad argument"); return LPX_EINVAL; }
+    if (!r->fused) { set_error("lpx_revised_profile: only the four-launch iteration is instrumented"); return LPX_EINVAL; }
+    if (iters > 512) iters = 512;
+    lpx_run_opts o; lpx_default_opts(&o, 1);
+    RvParams p = rv_params(r, &o);
+    LPX_HIP_TRY(hipStreamSynchronize(r->stream));
+    LPX_HIP_TRY(hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost));
+    DevState init = *r->hst;
+    const int iter0 = init.status == LPX_RUNNING || init.iter > 0 ? init.iter : 0;
+    init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = 2; init.iter = iter0;
+    init.dual_iter = iter0 + iters;                       // the iteration cap travels in the record
+    if (init.pad[0] <= 0) init.pad[0] = r->n;
+    *r->hst = init;
+    LPX_HIP_TRY(hipMemcpy(r->st, r->hst, sizeof(DevState), hipMemcpyHostToDevice));
+    std::vector<hipEvent_t> ev((size_t)8 * iters);
+    for (hipEvent_t& e : ev) LPX_HIP_TRY(hipEventCreate(&e));
+    const int chunks = (p.m + 127) / 128, per = (chunks + RVF_NW - 1) / RVF_NW;
+    for (int i = 0; i < iters; ++i) {
+        hipEvent_t* e = ev.data() + (size_t)8 * i;
+        if (per <= 1) rv_launch_fused_profiled<1>(p, r->stream, e); else if (per <= 2) rv_launch_fused_profiled<2>(p, r->stream, e);
+        else if (per <= 4) rv_launch_fused_profiled<4>(p, r->stream, e); else rv_launch_fused_profiled<8>(p, r->stream, e);
+    }
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(r->stream);
+    int rc = 0;
+    if (le != hipSuccess || se != hipSuccess) { set_error(std::string("lpx_revised_profile: ") + hipGetErrorString(le != hipSuccess ? le : se)); rc = LPX_EDEVICE; }
+    double sum[4] = {0, 0, 0, 0};
+    int done = 0;
+    if (!rc) {
+        if (hipMemcpy(r->hst, r->st, sizeof(DevState), hipMemcpyDeviceToHost) != hipSuccess) rc = LPX_EDEVICE;
+        done = rc ? 0 : std::min(iters, r->hst->iter - iter0);
+        for (int i = 0; i < done && !rc; ++i)
+            for (int k = 0; k < 4; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[(size_t)8 * i + 2 * k], ev[(size_t)8 * i + 2 * k + 1]) != hipSuccess) { rc = LPX_EDEVICE; set_error("lpx_revised_profile: event timing failed"); break; }
+                sum[k] += ms;
+            }
+    }
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) us[k] = done > 0 ? 1e3 * sum[k] / done : 0.0;
+    if (measured) *measured = done;
+    if (r->hst->status == LPX_ITER_LIMIT) {                // the cap of this profile run, not an outcome: the handle stays usable
+        r->hst->status = LPX_RUNNING;
+        LPX_HIP_TRY(hipMemcpy(r->st, r->hst, sizeof(DevState), hipMemcpyHostToDevice));
+    }
+    return rv_flush_pending(r);
 }
 
 int lpx_invert(const double* M, int n, double* inv)

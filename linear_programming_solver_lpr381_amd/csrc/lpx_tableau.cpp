@@ -143,8 +143,8 @@ int lpx_tableau_create(int R, int C, lpx_tableau** out)
                           up(sizeof(int32_t) * 2 * (size_t)t->trace_cap), up(sizeof(DevState)), up(sizeof(int32_t) * 2) };
     size_t total = 0;
     for (size_t b : sz) total += b;
-    hipError_t e_ = hipMalloc((void**)&t->T, tb);
-    if (e_ == hipSuccess) e_ = hipMalloc((void**)&t->slab, total);
+    hipError_t e_ = malloc_retry((void**)&t->T, tb);
+    if (e_ == hipSuccess) e_ = malloc_retry((void**)&t->slab, total);
     if (e_ != hipSuccess) {
         set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e_));
         lpx_tableau_destroy(t);
@@ -394,7 +394,7 @@ static bool fused_buffers(lpx_tableau* t)
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t tb = sizeof(double) * (size_t)t->Rcap * t->ld;
     const size_t sz[] = { up(sizeof(double) * t->ld), up(sizeof(double) * t->Rcap), up(2 * sizeof(DevState)) };
-    if (hipMalloc((void**)&t->fT, tb) != hipSuccess || hipMalloc((void**)&t->fslab, sz[0] + sz[1] + sz[2]) != hipSuccess) {
+    if (malloc_retry((void**)&t->fT, tb) != hipSuccess || malloc_retry((void**)&t->fslab, sz[0] + sz[1] + sz[2]) != hipSuccess) {
         (void)hipGetLastError();
         hipFree(t->fT); hipFree(t->fslab);
         t->fT = nullptr; t->fslab = nullptr; t->fused_off = true;
@@ -454,7 +454,7 @@ static int resident_buffers(lpx_tableau* t)
     LPX_HIP_TRY(hipMalloc((void**)&t->xp, xp_bytes(t)));
     LPX_HIP_TRY(hipMalloc((void**)&t->xgen, sizeof(unsigned)));
     LPX_HIP_TRY(hipMalloc((void**)&t->xbasis, sizeof(int32_t) * (size_t)t->Rcap));
-    LPX_HIP_TRY(hipMalloc((void**)&t->xT, sizeof(double) * (size_t)t->Rcap * t->ld));
+    LPX_HIP_TRY(malloc_retry((void**)&t->xT, sizeof(double) * (size_t)t->Rcap * t->ld));
     LPX_HIP_TRY(hipMemsetAsync(t->xr, 0, xr_bytes(t), t->stream));
     LPX_HIP_TRY(hipMemsetAsync(t->xp, 0, xp_bytes(t), t->stream));
     LPX_HIP_TRY(hipMemsetAsync(t->xgen, 0, sizeof(unsigned), t->stream));
@@ -1372,8 +1372,17 @@ std::multimap<size_t, void*> g_chunk_cache;
 size_t g_chunk_cached = 0;
 size_t chunk_cache_max()
 {
-    static const size_t v = [] { const char* e = std::getenv("LPX_STORE_CACHE_GB"); return (size_t)(e ? std::atoi(e) : 64) << 30; }();
+    // LPX_STORE_CACHE_GB (clamped to >= 0; default 64).  Whatever the cap, a chunk is only kept while a quarter of the device's memory
+    // stays free without it (chunk_release): several ranks sharing one GPU, or a big tableau allocated next, must not find the
+    // memory sitting idle in here -- and every large allocation of the library retries once after lpx::trim_device_caches().
+    static const size_t v = [] { const char* e = std::getenv("LPX_STORE_CACHE_GB"); long g = e ? std::atol(e) : 64; if (g < 0) g = 0; if (g > 4096) g = 4096; return (size_t)g << 30; }();
     return v;
+}
+void chunk_cache_drop_all()
+{
+    std::lock_guard<std::mutex> lk(g_chunk_mu);
+    for (auto& kv : g_chunk_cache) hipFree(kv.second);
+    g_chunk_cache.clear(); g_chunk_cached = 0;
 }
 hipError_t chunk_alloc(void** p, size_t bytes)
 {
@@ -1386,11 +1395,7 @@ hipError_t chunk_alloc(void** p, size_t bytes)
     if (e == hipSuccess) return e;
     // out of memory with chunks of other sizes in the cache: give them back and try once more
     (void)hipGetLastError();
-    {
-        std::lock_guard<std::mutex> lk(g_chunk_mu);
-        for (auto& kv : g_chunk_cache) hipFree(kv.second);
-        g_chunk_cache.clear(); g_chunk_cached = 0;
-    }
+    chunk_cache_drop_all();
     return hipMalloc(p, bytes);
 }
 void chunk_release(void* p, size_t bytes)
@@ -1398,11 +1403,27 @@ void chunk_release(void* p, size_t bytes)
     if (!p) return;
     {
         std::lock_guard<std::mutex> lk(g_chunk_mu);
-        if (g_chunk_cached + bytes <= chunk_cache_max()) { g_chunk_cache.emplace(bytes, p); g_chunk_cached += bytes; return; }
+        size_t free_b = 0, total_b = 0;
+        const bool roomy = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= total_b / 4;
+        if (roomy && g_chunk_cached + bytes <= chunk_cache_max()) { g_chunk_cache.emplace(bytes, p); g_chunk_cached += bytes; return; }
     }
     hipFree(p);
 }
 }  // namespace
+
+extern "C++" {
+namespace lpx {
+void trim_device_caches() { chunk_cache_drop_all(); }
+hipError_t malloc_retry(void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    trim_device_caches();
+    return hipMalloc(p, bytes);
+}
+}  // namespace lpx
+}  // extern "C++"
 
 struct lpx_store {
     int Rcap = 0, Ccap = 0, ld = 0, per_chunk = 128;
@@ -1426,6 +1447,9 @@ int lpx_store_create(int Rcap, int Ccap, lpx_store** out)
 void lpx_store_destroy(lpx_store* s)
 {
     if (!s) return;
+    // a chunk that enters the cache may be handed to another store at once: nothing (a parking copy, a child assembly reading a
+    // parked parent -- they run on the handles' streams) may still be using it.  hipFree used to give this wait for free.
+    if (!s->chunks_T.empty()) (void)hipDeviceSynchronize();
     for (double* p : s->chunks_T) chunk_release(p, sizeof(double) * s->slot_doubles * s->per_chunk);
     for (int32_t* p : s->chunks_b) chunk_release(p, sizeof(int32_t) * (size_t)s->Rcap * s->per_chunk);
     delete s;

@@ -92,6 +92,13 @@ class DeviceRevised:
         check(lib().lpx_revised_residual(self._h, C.byref(rel), C.byref(ab)))
         return rel.value, ab.value
 
+    def profile(self, iters: int = 200) -> dict:
+        """lpx_revised_profile: mean HIP-event microseconds per kernel of the four-launch iteration over `iters` real iterations."""
+        us = (C.c_double * 4)()
+        n = C.c_int()
+        check(lib().lpx_revised_profile(self._h, iters, us, C.byref(n)))
+        return {"rv_price": us[0], "rv_pick": us[1], "rv_upd_ftran": us[2], "rv_select2": us[3], "iterations": n.value}
+
     def refactor_stats(self) -> dict:
         a, b, c_, d, g, gc = C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
         check(lib().lpx_revised_refactor_stats(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(g), C.byref(gc)))

@@ -134,6 +134,17 @@ def main():
             res["peer_failure"].append({"error": None, "allreduces": calls["n"]})
         except L.SolverException as e:
             res["peer_failure"].append({"error": str(e), "code": e.code, "allreduces": calls["n"]})
+    # --- ranks whose replicated warm-up DIFFERS (here: rank 1 is handed another objective; in round 2 it was a kernel whose result
+    #     depended on workgroup scheduling): the fingerprint in the first all-reduce tells every rank, nobody waits in a collective
+    c_alt = c.copy(); c_alt[:3] += 7.0
+    p_alt = L.LPProblem.from_arrays(0, c_alt if rank == 1 else c, Af, np.zeros(m + n, int), bf)
+    calls["n"] = 0
+    try:
+        L.BranchAndBound(bnb_mode=1, bnb_search=1, concurrent_nodes=2, rank=rank, world=world,
+                         allreduce_max=allreduce_max, test_node_lp=node_lp).Solve(p_alt)
+        res["divergence"] = {"error": None, "allreduces": calls["n"]}
+    except L.SolverException as e:
+        res["divergence"] = {"error": str(e), "allreduces": calls["n"]}
     dist.barrier()
     dist.destroy_process_group()
     json.dump(res, open(out, "w"))

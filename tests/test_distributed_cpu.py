@@ -72,6 +72,10 @@ def test_world2_gloo_bnb_and_knapsack(tmp_path, lpx, oracle):
         assert f0["error"] and "peer rank failed" in f0["error"], f0
         assert f1["error"] and "injected failure" in f1["error"] and f1["code"] == -3, f1
         assert f0["allreduces"] == f1["allreduces"] >= 1
+    # ranks that disagree about the replicated warm-up find out in their first all-reduce and all return an error
+    for r in res:
+        assert r["divergence"]["error"] and "ended differently on different ranks" in r["divergence"]["error"], r["divergence"]
+    assert res[0]["divergence"]["allreduces"] == res[1]["divergence"]["allreduces"] == 1
 
 
 def test_comm_id_handover_over_tcp(lpx):
