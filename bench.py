@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "simplex pivots/sec on dense m×n tableau; B&B nodes/sec at 1/2/4/8 GPUs"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def update_kernel(R, C):
@@ -146,8 +146,9 @@ def launch_ranks(n):
     sys.exit(0)
 
 
-WARM_NOTE = ("batched streaming kernels of the dual loop, rolling batches of node LPs refilled when half of them have finished "
-             "(lpx_multi_run_some)")
+WARM_NOTE = ("one launch per step for the whole batch (lpx_group_fused: update out of place beside the select of every live node, the live "
+             "list compacted on the device from launch to launch); two rolling batches alternate (lpx_multi_run_begin / _end), so the host "
+             "reads back, parks and refills one while the other pivots")
 LEGS = ("bnb", "bnb_warm", "bnb_prune", "bnb_prune_mid", "knapsack", "roofline", "config2", "revised", "cpu")
 
 
@@ -441,6 +442,34 @@ def main():
             res["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": rate, "frac": rate / HBM_PEAK_GBS,
                                "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
                                "note": WARM_NOTE}
+            if rank == 0:
+                # the leg's kernel by itself: lpx_group_fused on 64 copies of the root tableau pivoting in lock step (every slot live), HIP
+                # events bound to each launch; traffic = the committed PMC passes of the same launch shape (tools/k4_headline.py)
+                Tb_, basb_ = synth.primal_tableau_from(cb, Ab, bb)
+                K_ = 64
+                nodes_ = [L.DeviceTableau.from_host(Tb_, basb_) for _ in range(K_)]
+                L.multi_run(nodes_, [False] * K_, L.default_opts(False, max_iter=64, resident=-1), L.default_opts(True, resident=-1))
+                for t_ in nodes_:
+                    t_.upload(Tb_, basb_)
+                _, gss = L.multi_run(nodes_, [False] * K_, L.default_opts(False, max_iter=192, resident=-1, profile=1),
+                                     L.default_opts(True, resident=-1, profile=1))
+                for t_ in nodes_:
+                    t_.close()
+                if gss[0]["update_launches"] > 0:
+                    g_us = 1e3 * gss[0]["update_ms_sum"] / gss[0]["update_launches"]
+                    g_alg = K_ * 16.0 * R0 * C0
+                    g_ach = g_alg / (g_us * 1e-6) / 1e9
+                    pmcg, pmcg_src = committed_profile("pmc_traffic.json")
+                    g_tr = None
+                    if pmcg:
+                        hit = [v for k_, v in pmcg.items() if "lpx_group_fused" in k_]
+                        if hit:
+                            g_tr = max(hit, key=lambda v: v["hbm_bytes_per_launch"])["hbm_bytes_per_launch"]
+                    res["kernel"] = {"kernel": "lpx_group_fused", "bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": g_ach / HBM_PEAK_GBS, "traffic": g_tr, "traffic_source": pmcg_src if g_tr else None,
+                                     "algorithmic_bytes_per_launch": g_alg, "avg_kernel_us": g_us, "launches": gss[0]["update_launches"],
+                                     "shape": f"{K_} node tableaux of {R0}x{C0}, every slot live",
+                                     "timing": "HIP start/stop events bound to each dispatch on the library stream, this run"}
             out["bnb_warm"] = res
         # ---- a 0/1 IP small enough to be SOLVED: incumbents appear, the all-reduced bound prunes, pools are rebalanced ----
         if leg("bnb_prune"):

@@ -35,6 +35,16 @@ status, st = rv.run(max_iter=npiv, batch=20, use_graph=0)
 print("revised iterations", st["pivots"], "status", status)
 rv.close()
 del A3
+# config 4's streaming group step (lpx_group_fused: update out of place beside the select of every live node): 64 copies of the root
+# tableau (769 x 1281) pivoting in lock step, i.e. full liveness -- algorithmic bytes per launch = 64 x 16 x 769 x 1281
+from linear_programming_solver_lpr381_amd._lib import default_opts
+cb, Ab, relb, bb = synth.binary_ip(512, 256)
+Tb, basb = synth.primal_tableau_from(cb, Ab, bb)
+nodes = [L.DeviceTableau.from_host(Tb, basb) for _ in range(64)]
+stg, ssg = L.multi_run(nodes, [False] * 64, default_opts(False, max_iter=npiv, resident=-1, batch=20), default_opts(True, resident=-1))
+print("group steps", ssg[0]["pivots"], "statuses", set(stg))
+for t_ in nodes:
+    t_.close()
 # config 5: the knapsack expansion kernel (bytes per bound: per-launch traffic / (grid / 64 jobs x 3 bounds))
 pk, wk, capk = synth.knapsack(100_000)
 kp = L.LPProblem(L.Sense.Max, pk.tolist(), [L.Constraint(wk.tolist(), L.Rel.LE, capk)])

@@ -19,7 +19,7 @@ write = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for key in sorted(set(fetch) | set(write)):
     name, grid = key
-    if not any(k in name for k in ("lpx_update", "lpx_pivot_fused", "lpx_resident", "rv_price", "rv_upd_ftran", "rv_flush", "knap_expand")):
+    if not any(k in name for k in ("lpx_update", "lpx_pivot_fused", "lpx_group_fused", "lpx_resident", "rv_price", "rv_upd_ftran", "rv_flush", "knap_expand")):
         continue
     f = fetch.get(key, []); w = write.get(key, [])
     # drop early-exit launches (tail of a batch after the loop has finished: they read the state record and leave)
