@@ -166,10 +166,13 @@ __device__ unsigned long long lpx_g_stamps[32];
 // FLY = true: sources in LDS -- each ratio is formed as soon as its two operands are read, so only the 16 ratios
 // stay live (32 VGPRs instead of 96; the resident kernels have 128 per lane and spill otherwise).
 // (seg0, best0, win0): continue a scan whose segments before row seg0 ended with the carried (best, position).
-template <class Src, bool FLY = false>
+// PER: ratios per lane and segment (default WH_PER = 16).  The chain is exact for any segment length (best and position are carried
+// across segments); a kernel that is short of registers (lpx_resident_regs.hip: the tableau tile lives in VGPRs) scans with PER = 4.
+template <class Src, bool FLY = false, int PER = 16>
 __device__ __forceinline__ int wave_hysteresis_argmin(int L, double tol, const Src& src,
                                                       int seg0 = 0, double best0 = __builtin_inf(), int win0 = -1)
 {
+    constexpr int WH_PER = PER;
     const int lane = threadIdx.x & 63;
     double best = best0;
     int win = win0;

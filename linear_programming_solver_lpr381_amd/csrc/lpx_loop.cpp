@@ -30,6 +30,7 @@ int ensure_device()
     }
     std::call_once(g_init_once, [] { g_init_err = kernels_init(); if (g_init_err == hipSuccess) g_init_err = resident_init();
                                      if (g_init_err == hipSuccess) g_init_err = resident_group_init();
+                                     if (g_init_err == hipSuccess) g_init_err = resident_regs_init();
                                      if (g_init_err == hipSuccess) g_init_err = resident_col_init(); });
     if (g_init_err != hipSuccess) {
         set_error(std::string("kernel attribute setup failed: ") + hipGetErrorString(g_init_err));

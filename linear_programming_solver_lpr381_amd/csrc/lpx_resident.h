@@ -58,6 +58,28 @@ __device__ __forceinline__ bool rs_gather(const u64* g, const int* idx, int coun
     return pending == 0;
 }
 
+// Two granule pairs per round instead of four: half the registers (the register-resident kernel, whose workgroups are as wide as
+// the vectors they gather, never needs more than two per lane).
+__device__ __forceinline__ bool rs_gather2(const u64* g, int i0, int i1, int count, unsigned gen, double* out,
+                                           unsigned max_spin = RS_SPIN_MAX, unsigned* pend = nullptr)
+{
+    unsigned pending = pend ? *pend : (1u << count) - 1u;
+    const u64* p0 = g + 2 * (size_t)i0;
+    const u64* p1 = g + 2 * (size_t)(count > 1 ? i1 : i0);
+    for (unsigned spin = 0; spin < max_spin && pending; ++spin) {
+        rs_u4 w0, w1;
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                     "global_load_dwordx4 %1, %3, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1) : "v"(p0), "v"(p1) : "memory");
+        if ((pending & 1u) && w0.y == gen && w0.w == gen) { out[0] = __longlong_as_double((long long)(((u64)w0.z << 32) | (u64)w0.x)); pending &= ~1u; }
+        if ((pending & 2u) && w1.y == gen && w1.w == gen) { out[1] = __longlong_as_double((long long)(((u64)w1.z << 32) | (u64)w1.x)); pending &= ~2u; }
+        if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
+    }
+    if (pend) *pend = pending;
+    return pending == 0;
+}
+
 // Waits until one granule pair carries generation `gen` (same address in every lane: one request per wave).
 __device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
 {

@@ -1,0 +1,422 @@
+// lpx_resident_regs.hip -- the resident group loop of lpx_resident_group.hip with the node's rows in REGISTERS instead of LDS.
+//
+// Cold branch-and-bound nodes (every node re-solved from the slack basis as the reference does, Models/Branch&Bound.cs:148) are
+// bound by what fits on chip: four 7.9 MB tableaux fill the 40 MB of LDS, and the loop is latency bound (two cross-CU exchanges per
+// pivot), so the chip idles through most of a step.  The register files hold three times as much as the LDS (512 KB per CU,
+// 128 MB in all).  Here workgroup w of a node keeps RPW consecutive rows in VGPRs: lane t owns the column pair (2t, 2t+1) of every
+// one of them (a workgroup is as wide as the tableau: NT >= ld / 2 lanes), so
+//   * the rank-1 update is register arithmetic (row factor broadcast from LDS, the lane's pivot-row pair read once per pivot);
+//   * a COLUMN of the local rows (entering column -> factors; RHS and next entering column -> the ratios the rows publish) is
+//     the RPW registers of ONE lane, which drops them into LDS;
+//   * the pivot ROW of the owner is register `rl` of every lane, `rl` workgroup-uniform but dynamic: an unrolled select chain.
+// With fewer lanes per CU a lane gets more registers: NT = 768 -> 3 waves per SIMD -> 168 VGPRs -> 28 rows of a 1282-column node per
+// workgroup -> 28 workgroups per node -> NINE config-4 nodes in flight instead of four.  Everything else -- the tagged-granule
+// exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
+// lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
+// the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB.
+#include "lpx_resident.h"
+#include <cstdlib>
+
+namespace lpx {
+
+struct ResGroupParamsR { const ResNode* nodes; int chunk; int mute; };
+
+#ifdef LPX_STAMPS
+#define RR_T0 unsigned long long rg_prev_ = __builtin_amdgcn_s_memtime();
+#define RR_T(slot) do { if (threadIdx.x == 0 && blockIdx.x == (gridDim.x > 1 ? 1 : 0) && blockIdx.y == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); P.xp[4 * ((size_t)P.ld + 8) + (slot)] += n_ - rg_prev_; rg_prev_ = n_; } } while (0)
+#else
+#define RR_T0
+#define RR_T(slot) do {} while (0)
+#endif
+
+// rs_hysteresis (lpx_resident.h) with the exact replay INLINE and four ratios per lane and segment: the replay of lpx_resident.h is a
+// real call, and a call makes the caller save its live registers -- here the whole register tile (28 dwordx4 stores and loads through
+// scratch per call, on the critical path of almost every pivot of a 0/1 program: its ratios tie all the time).
+__device__ __forceinline__ int rr_hysteresis(int m, double tol, const double* ratios, double* s_v, int* s_i, int* s_out)
+{
+    const int t = threadIdx.x;
+    MinIdx lm; lm.v = __builtin_inf(); lm.i = INT_MAX;
+    if (t < RS_RT)
+        for (int i = t; i < m; i += RS_RT) { const double v = ratios[i]; if (v < lm.v) { lm.v = v; lm.i = i; } }
+    lm = first4_min_idx(lm, s_v, s_i);
+    int r;
+    if (lm.i == INT_MAX) { r = -1; __syncthreads(); }
+    else {
+        if (t < RS_RT) {
+            int inband = 0;
+            for (int i = t; i < m; i += RS_RT) inband += ((ratios[i] - tol) <= lm.v) ? 1 : 0;
+            const int wsum = __popcll(__ballot(inband == 1)) + 2 * __popcll(__ballot(inband >= 2));
+            if ((t & 63) == 0) s_i[4 + (t >> 6)] = wsum;
+        }
+        __syncthreads();
+        if (s_i[4] + s_i[5] + s_i[6] + s_i[7] == 1) r = lm.i;
+        else {
+            if ((t >> 6) == 0) {
+                const int win = wave_hysteresis_argmin<LdsRatio, true, 4>(m, tol, LdsRatio{ratios});
+                if (t == 0) *s_out = win;
+            }
+            __syncthreads();
+            r = *s_out;
+        }
+        __syncthreads();
+    }
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ int rr_first_min_below(const double* v, int L, double eps, double* s_v, int* s_i)
+{
+    MinIdx m; m.v = -eps; m.i = INT_MAX;
+    if (threadIdx.x < RS_RT)
+        for (int j = threadIdx.x; j < L; j += RS_RT) { const double x = v[j]; if (x < m.v) { m.v = x; m.i = j; } }
+    m = first4_min_idx(m, s_v, s_i);
+    __syncthreads();
+    return m.i == INT_MAX ? -1 : m.i;
+}
+
+// WPE = waves per SIMD the kernel is compiled for (NT / 256): sets the register budget
+template <int NT, int RPW, int WPE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void lpx_resident_group_r(ResGroupParamsR GP)
+{
+    extern __shared__ __align__(16) double rr_lds[];
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ int s_out;
+
+    const ResNode& N = GP.nodes[blockIdx.y];
+    struct { double* T; int ld, R, C; unsigned long long* xr; unsigned long long* xp; int mcap, dual; } P;
+    P.T = N.T; P.ld = N.ld; P.R = N.R; P.C = N.C; P.xr = N.xr; P.xp = N.xp; P.mcap = N.mcap; P.dual = N.dual;
+    const double eps = N.eps;
+    DevState* st = N.st;
+    if (st->status != LPX_RUNNING) return;
+    if ((GP.mute == 1 || (GP.mute == 2 && st->iter > 0)) && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) return;   // plays dead
+    if (rs_abort_raised(st)) return;
+    if (GP.mute == 3 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) rs_wait_for_abort(st);
+    const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
+    const int C = P.C, m = P.R - 1, rhsc = C - 1;
+    const int rpw = (m + G - 1) / G;            // <= RPW (host)
+    const int row0 = w * rpw;
+    const int nloc = max(0, min(rpw, m - row0));
+    const int mp = (m + 1) & ~1;
+    const int gld = P.ld;
+    const int ld = (C + 1) & ~1;                // width of the register tile: NT >= ld / 2 (host)
+    double* obj = rr_lds;                       // [ld]
+    double* prow = obj + ld;                    // [ld]
+    double* rowbuf = prow + ld;                 // [ld]   the owner's pivot row as it stands (before the division)
+    double* col = rowbuf + ld;                  // [mp]   gathered per-row values
+    double* fac = col + mp;                     // [RPW+1]
+    double* ca = fac + RPW + 1;                 // [RPW]  column qc of the local rows
+    double* cr = ca + RPW;                      // [RPW]  RHS column of the local rows, kept current from round to round (as the tile's own)
+    double* fn = cr + RPW;                      // [RPW]  column qc as the lookahead left it = the next pivot's factors when it enters
+
+    const int jt = 2 * t;                       // this lane's column pair
+    const bool mine = jt < ld;
+    double2 reg[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        reg[i] = make_double2(0.0, 0.0);
+        if (i < nloc && mine) reg[i] = *reinterpret_cast<const double2*>(P.T + (size_t)(row0 + i) * gld + jt);
+    }
+    {
+        const double* src = P.T + (size_t)m * gld;
+        for (int j = 2 * t; j < ld; j += 2 * NT) {
+            *reinterpret_cast<double2*>(obj + j) = *reinterpret_cast<const double2*>(src + j);
+            *reinterpret_cast<double2*>(prow + j) = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
+    // column c of the local rows -> dst[0..RPW): the registers of the one lane that owns it
+    auto column_out = [&](int c, double* dst) __attribute__((always_inline)) {
+        if (t == (c >> 1)) {
+            // the odd / even half by bit masks: written as `odd ? reg[i].y : reg[i].x` the compiler turns the select of two values into a
+            // select of two ADDRESSES and moves the whole register tile into scratch memory (480 bytes per lane, 4.6x slower per step)
+            const long long mk = -(long long)(c & 1);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+                dst[i] = __longlong_as_double((__double_as_longlong(reg[i].x) & ~mk) | (__double_as_longlong(reg[i].y) & mk));
+        }
+    };
+
+    int phase = P.dual ? st->phase : 2;
+    int fdf_count = st->fdf_count, dual_iter = st->dual_iter, primal_count = st->primal_count, iter = st->iter;
+    unsigned gen = *N.xgen;
+    int status = LPX_RUNNING;
+    bool hung = false;
+    int r = -1, qlast = -1;
+    int qc = (phase != 1) ? rr_first_min_below<NT>(obj, rhsc, eps, s_v, s_i) : -1;
+    bool publish_now = GP.chunk > 0;
+    // A column of the local rows costs its owner lane RPW masked moves and LDS stores (~0.3 us): the RHS column is therefore kept as
+    // an LDS replica that the lookahead advances with the tile's own arithmetic, and the column the lookahead corrected for the next
+    // ratio test IS the next pivot's factor column when that column enters (fn, valid for column fn_col)
+    column_out(rhsc, cr);
+    int fn_col = -1;
+
+    RR_T0
+    for (int k = 0; k < GP.chunk; ++k) {
+        if (publish_now) {
+            if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
+            if (phase != 1 && qc >= 0) column_out(qc, ca);
+            __syncthreads();
+            if (t < nloc) {
+                const double rhs0 = cr[t];
+                double v = rhs0;
+                if (phase != 1) { const double a0 = qc >= 0 ? ca[t] : 0.0; v = a0 > eps ? rhs0 / a0 : __builtin_inf(); }   // :229-233
+                rs_publish(P.xr + 2 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t), v, gen + 1u);
+            }
+            publish_now = false;
+        }
+        ++gen;
+        const int par = (int)(gen & 1u);
+        // ---- exchange 1: one value per row ----------------------------------------------------------------------------
+        int fail = 0;
+        for (int base = t; base < m; base += NT * 2) {
+            double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < m ? 2 : 1;
+            if (!rs_gather2(P.xr + 2 * (size_t)par * P.mcap, i0, i1, cnt, gen, val)) fail = 1;
+            col[i0] = val[0];
+            if (cnt > 1) col[i1] = val[1];
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+        RR_T(1);
+
+        // ---- the decision of lpx_select_body, replicated (as lpx_resident_group) ------------------------------------------
+        int q = -1, final_status = LPX_RUNNING;
+        bool republish = false;
+        r = -1;
+        for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0 && !republish; ++hop) {
+            if (phase == 1) {
+                if (dual_iter >= N.max_iter) { final_status = LPX_ITER_LIMIT; break; }
+                r = rr_first_min_below<NT>(col, m, eps, s_v, s_i);
+                if (r < 0) {
+                    if (N.cleanup) {
+                        const int qe = rr_first_min_below<NT>(obj, rhsc, eps, s_v, s_i);
+                        if (qe >= 0) { phase = 2; qc = qe; republish = true; break; }
+                    }
+                    final_status = LPX_OPTIMAL; break;
+                }
+                q = -2;
+            } else {
+                if (phase == 0 && fdf_count >= N.fdf_guard) { phase = 1; qc = -1; republish = true; break; }
+                if (phase == 2 && primal_count >= N.max_iter - dual_iter) { final_status = LPX_ITER_LIMIT; break; }
+                q = qc;
+                if (q < 0) { if (phase == 0) { phase = 1; qc = -1; republish = true; break; } final_status = LPX_OPTIMAL; break; }
+                r = rr_hysteresis(m, phase == 0 ? N.tol_fdf : N.tol_primal, col, s_v, s_i, &s_out);
+                if (r < 0) { q = -1; if (phase == 0) { phase = 1; qc = -1; republish = true; break; } final_status = LPX_UNBOUNDED; break; }
+            }
+        }
+        if (republish) { publish_now = true; continue; }
+        if (final_status != LPX_RUNNING || r < 0) { status = (final_status == LPX_RUNNING) ? LPX_OPTIMAL : final_status; break; }
+
+        RR_T(2);
+        // ---- exchange 2: the owner normalises row r (and, in the dual loop, chooses the entering column) ------------------
+        const int owner = r / rpw, rl = r - owner * rpw;
+        u64* xp = P.xp + 2 * (size_t)par * (gld + 8);
+        if (w == owner) {
+            // the pivot row out of the registers: register `rl` of every lane (rl is uniform, the chain is unrolled)
+            if (mine) {
+                double2 v = reg[0];
+#pragma unroll
+                for (int i = 1; i < RPW; ++i) if (i == rl) v = reg[i];
+                *reinterpret_cast<double2*>(rowbuf + jt) = v;
+            }
+            __syncthreads();
+            if (phase == 1) {                                                   // entering column of the dual loop, :79-91
+                if ((t >> 6) == 0) {
+                    const int win = wave_hysteresis_argmin<DualColRatio, true, 4>(rhsc, N.tol_dual, DualColRatio{rowbuf, obj, eps});
+                    if (t == 0) s_out = win;
+                }
+                __syncthreads();
+                q = s_out;
+            }
+            if (q >= 0) {
+                const double piv = rowbuf[q];
+                for (int j = t; j < C; j += NT) {
+                    const double p = rowbuf[j] / piv;                           // true division, :250
+                    rs_publish(xp + 2 * (size_t)j, p, gen);
+                    prow[j] = p;
+                }
+            }
+            if (phase == 1) {
+                __syncthreads();
+                if (t == 0) rs_publish(xp + 2 * (size_t)gld, (double)q, gen);   // header {q} behind the row
+            }
+        } else if (phase != 1) {
+            __builtin_amdgcn_s_sleep(15);
+            for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
+            bool first = true;
+            for (int base = t; base < C; base += NT * 2) {
+                double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < C ? 2 : 1;
+                unsigned pend = (1u << cnt) - 1u;
+                if (first && !rs_gather2(xp, i0, i1, cnt, gen, val, 1u, &pend)) {
+                    if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
+                }
+                first = false;
+                if (pend && !rs_gather2(xp, i0, i1, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
+                prow[i0] = val[0];
+                if (cnt > 1) prow[i1] = val[1];
+            }
+        } else {
+            __builtin_amdgcn_s_sleep(15);
+            for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
+            __builtin_amdgcn_s_sleep(25);                                       // the owner scans its row first
+            // the header first (one granule, the same address in every lane), then the row
+            {
+                double hval[2];
+                if (!rs_gather2(xp, gld, gld, 1, gen, hval)) fail = 1;
+                q = fail ? -1 : (int)hval[0];
+            }
+            if (q >= 0)
+                for (int base = t; base < C; base += NT * 2) {
+                    double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < C ? 2 : 1;
+                    if (!rs_gather2(xp, i0, i1, cnt, gen, val)) fail = 1;
+                    prow[i0] = val[0];
+                    if (cnt > 1) prow[i1] = val[1];
+                }
+        }
+        if (__syncthreads_or(fail)) { hung = true; break; }
+        if (q < 0) { r = -1; status = LPX_INFEASIBLE; break; }                  // :92-96 (dual loop only)
+        RR_T(3);
+
+        // ---- column factors of this pivot, objective replica, next entering column ------------------------------------------
+        if (fn_col == q) { if (t < RPW) fac[t] = fn[t]; }                       // the lookahead of the last round already formed this column
+        else column_out(q, fac);
+        if (t == NT - 1) fac[RPW] = obj[q];
+        __syncthreads();
+        const double fobj = fac[RPW];
+        const int skip = (w == owner) ? rl : -1;
+        MinIdx best; best.v = -eps; best.i = INT_MAX;
+        if (t < RS_RT) {
+            for (int j = 2 * t; j < ld; j += 2 * RS_RT) {
+                const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                double2 o = *reinterpret_cast<double2*>(obj + j);
+                double prod = fobj * p.x; o.x = o.x - prod;
+                prod = fobj * p.y; o.y = o.y - prod;
+                *reinterpret_cast<double2*>(obj + j) = o;
+                if (j < rhsc && o.x < best.v) { best.v = o.x; best.i = j; }
+                if (j + 1 < rhsc && o.y < best.v) { best.v = o.y; best.i = j + 1; }
+            }
+        }
+        best = first4_min_idx(best, s_v, s_i);
+        if (w == 0 && t == 0) {
+            N.basis[r] = q;                                                     // basis[leaving] = entering, :110
+            if (iter < N.trace_cap) { N.trace[2 * iter] = r; N.trace[2 * iter + 1] = q; }
+        }
+        qlast = q;
+        ++iter;
+        if (phase == 0) ++fdf_count; else if (phase == 1) ++dual_iter; else ++primal_count;
+        qc = (phase != 1) ? (best.i == INT_MAX ? -1 : best.i) : -1;
+        RR_T(4);
+        // ---- lookahead: next round's per-row values leave before the bulk of the update ------------------------------------
+        const bool look = k + 1 < GP.chunk;
+        if (look) {
+            if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
+            if (qc >= 0) column_out(qc, ca);                                    // column qc as it stands BEFORE this pivot's update
+        }
+        __syncthreads();
+        fn_col = -1;
+        if (look) {
+            if (t < nloc) {
+                double a = 0.0, rhs;
+                if (t == skip) { if (qc >= 0) a = prow[qc]; rhs = prow[rhsc]; }
+                else {
+                    const double f = fac[t];
+                    if (qc >= 0) { const double prod = f * prow[qc]; a = ca[t] - prod; }
+                    const double prod2 = f * prow[rhsc]; rhs = cr[t] - prod2;
+                }
+                cr[t] = rhs;                                                    // the RHS replica moves on with the tile
+                if (qc >= 0) fn[t] = a;
+                const double v = (phase == 1) ? rhs : (a > eps ? rhs / a : __builtin_inf());
+                rs_publish(P.xr + 2 * ((size_t)(par ^ 1) * P.mcap + row0 + t), v, gen + 1u);
+            }
+            if (qc >= 0) fn_col = qc;
+        }
+        RR_T(0);
+        // ---- rank-1 update of the local rows in registers, :250-256.  Straight-line over all RPW registers: rows beyond nloc hold
+        //      dummies nobody reads, and the owner's pivot row -- which the update must leave alone (:252) -- is put back afterwards
+        //      from the normalised row (a predicate per row would cost two scalar mask registers each, hoisted out of the round loop)
+        if (mine) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + jt);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const double f = fac[i];
+                double prod = f * p.x; reg[i].x = reg[i].x - prod;
+                prod = f * p.y; reg[i].y = reg[i].y - prod;
+            }
+            if (skip >= 0) {                                                    // row r of the owner = the normalised pivot row, :249-250
+                double2 v = p;
+                if (jt + 1 >= C) v.y = rowbuf[jt + 1 < ld ? jt + 1 : jt];       // the padding column keeps what it held
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) if (i == skip) reg[i] = v;
+            }
+        }
+        __syncthreads();                        // fac / ca / cr / prow / rowbuf are rewritten by the next round
+        RR_T(5);
+    }
+
+    if (hung) {
+        if (t == 0) { atomicOr(&st->pad[1], 1); if (N.st_host) N.st_host->pad[1] = 1; }
+        return;
+    }
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+            if (i < nloc) *reinterpret_cast<double2*>(P.T + (size_t)(row0 + i) * gld + jt) = reg[i];
+    }
+    if (w == 0) {
+        double* dst = P.T + (size_t)m * gld;
+        for (int j = 2 * t; j < ld; j += 2 * NT)
+            *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(obj + j);
+        if (t == 0) {
+            st->status = status; st->iter = iter; st->phase = phase;
+            st->fdf_count = fdf_count; st->dual_iter = dual_iter; st->primal_count = primal_count;
+            st->r = status == LPX_RUNNING ? r : -1; st->q = status == LPX_RUNNING ? qlast : -1;
+            if (DevState* hm = N.st_host) {
+                hm->status = status; hm->iter = iter; hm->phase = phase;
+                hm->fdf_count = fdf_count; hm->dual_iter = dual_iter; hm->primal_count = primal_count;
+                hm->r = status == LPX_RUNNING ? r : -1; hm->q = status == LPX_RUNNING ? qlast : -1;
+            }
+            *N.xgen = gen;
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+// shapes the register kernel is instantiated for: (lanes, rows per workgroup)
+static constexpr int RR_NT_A = 768, RR_RPW_A = 22;     // tableaux up to 1536 columns: config 4 and its branching levels
+static constexpr int RR_NT_B = 512, RR_RPW_B = 48;     // up to 1024 columns
+
+size_t resident_regs_lds(int R, int C, int rpw_max)
+{
+    const int m = R - 1, ld = (C + 1) & ~1;
+    return sizeof(double) * ((size_t)3 * ld + (size_t)((m + 1) & ~1) + (size_t)4 * rpw_max + 2);
+}
+
+// 0 = this group does not fit the register kernel; else the workgroup size, with *rpw_max the rows a workgroup can hold
+int resident_regs_shape(int maxC, int* rpw_max)
+{
+    const int ld = (maxC + 1) & ~1;
+    if (ld <= 2 * RR_NT_B) { *rpw_max = RR_RPW_B; return RR_NT_B; }
+    if (ld <= 2 * RR_NT_A) { *rpw_max = RR_RPW_A; return RR_NT_A; }
+    return 0;
+}
+
+hipError_t resident_regs_init()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return e;
+}
+
+hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int nt, size_t lds, int chunk, hipStream_t s)
+{
+    ResGroupParamsR p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
+    static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
+    p.mute = mute;
+    if (nt == RR_NT_A) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);
+    else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2>), dim3(grid, nodes), dim3(RR_NT_B), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lpx

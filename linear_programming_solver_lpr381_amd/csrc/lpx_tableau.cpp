@@ -563,8 +563,34 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
 struct ResGroupBuf { ResNode* d = nullptr; ResNode* h = nullptr; DevState* hs = nullptr; int cap = 0; hipStream_t stream = nullptr; };
 ResGroupBuf g_resgroup;
 
+// which kernel the last resident_group_plan chose: 0 = rows in LDS (lpx_resident_group), else the workgroup size of the
+// register-resident variant (lpx_resident_group_r); read by run_resident_group right after (handles are used from one thread)
+static thread_local int tl_plan_nt = 0;
+
+// The register-resident variant (node rows in VGPRs): more nodes per launch when a node is wide enough to need many CUs' LDS.
+// Returns the nodes per launch it would give (0 = not applicable) and fills grid / lds / nt.
+static int resident_regs_plan(lpx_tableau** ts, int count, int cus, int* grid, size_t* lds, int* nt)
+{
+    static const bool enabled = [] { const char* e = std::getenv("LPX_RESIDENT_REGS"); return !(e && e[0] == '0'); }();
+    if (!enabled) return 0;
+    int maxC = 2, mmax = 1, mmin = 1 << 30;
+    for (int i = 0; i < count; ++i) { maxC = std::max(maxC, ts[i]->C); mmax = std::max(mmax, ts[i]->R - 1); mmin = std::min(mmin, ts[i]->R - 1); }
+    int rpw_max = 0;
+    const int n = resident_regs_shape(maxC, &rpw_max);
+    if (!n) return 0;
+    int g = (mmax + rpw_max - 1) / rpw_max;                 // workgroups per node: every node's rows per workgroup <= rpw_max
+    if (g > mmin || g > cus) return 0;
+    { const int rpw = (mmax + g - 1) / g; g = (mmax + rpw - 1) / rpw; }          // no idle workgroups for the tallest node
+    size_t need = 0;
+    for (int i = 0; i < count; ++i) need = std::max(need, resident_regs_lds(ts[i]->R, ts[i]->C, rpw_max));
+    if (need > (size_t)96 * 1024) return 0;
+    *grid = g; *lds = need; *nt = n;
+    return cus / g;
+}
+
 int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size_t* lds)
 {
+    tl_plan_nt = 0;
     hipDeviceProp_t prop; int dev = 0;
     static int cus = 0;
     if (!cus) { if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0; cus = prop.multiProcessorCount; }
@@ -594,7 +620,20 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
         }
         need = 0;
         for (int i = 0; i < count; ++i) { const size_t b = resident_group_lds(ts[i]->R, ts[i]->C, ts[i]->ld, g); if (b > need) need = b; }
-        if (need <= lds_max) { *grid = g; *slots = n; *lds = need; return 1; }
+        if (need <= lds_max) {
+            *grid = g; *slots = n; *lds = need;
+            // rows in registers instead, when that puts more nodes on the chip at once (and there are enough nodes to use them)
+            int rg = 0, rnt = 0; size_t rlds = 0;
+            const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt);
+            static const bool force_regs = [] { const char* e = std::getenv("LPX_RESIDENT_REGS"); return e && e[0] == '2'; }();   // diagnostic: whenever it applies
+            if (rslots >= 1 && (force_regs || (rslots > n && count > n))) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; }
+            return 1;
+        }
+    }
+    {   // nothing fits the LDS form: the register form alone
+        int rg = 0, rnt = 0; size_t rlds = 0;
+        const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt);
+        if (rslots >= 1) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; return 1; }
     }
     return 0;
 }
@@ -604,6 +643,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
                        DevState* resume = nullptr)
 {
     ResGroupBuf& g = g_resgroup;
+    const int plan_nt = tl_plan_nt;             // 0: rows in LDS; else lanes per workgroup of the register-resident kernel
     if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (g.cap < count) {
         hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
@@ -663,7 +703,8 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         }
         // the kernel writes each node's new state into the pinned mirror (ResNode::st_host): nothing is copied back
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
-        LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
+        if (plan_nt) LPX_HIP_TRY(launch_resident_regs(g.d, n, grid, plan_nt, lds, chunk, g.stream));
+        else LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
         LPX_HIP_TRY(hipStreamSynchronize(g.stream));
         bool aborted = false;
         for (int k = 0; k < n; ++k) if (g.hs[live[k]].pad[1]) aborted = true;
