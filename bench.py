@@ -426,11 +426,12 @@ def main():
                                      "fractional basic variables, one is fixed per level and SolveNode stops at depth 200 "
                                      "(Models/Branch&Bound.cs:25,132) -- a depth-first-K dive of 4000 nodes ends in 'maximum depth' "
                                      "leaves (tools/probe_bnb.py); the shared bound is exercised by `bnb_prune` / `bnb_prune_mid` below")
-            # NOT a roofline fraction: the node tableaux of this leg live in LDS, HBM sees each once per launch
+            # NOT a roofline fraction: the node tableaux of this leg live on chip (registers / LDS), HBM sees each once per launch
             res["hbm_equivalent"] = {"unit": "GB/s", "value": hbm_equivalent(res), "bound": "latency",
                                      "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
-                                     "note": "the rate a streaming implementation would have to sustain to match this leg; the node tableaux "
-                                             "live in LDS (lpx_resident_group), so this is not HBM traffic and no fraction of the HBM peak"}
+                                     "note": "the rate a streaming implementation would have to sustain to match this leg; the node tableaux live on "
+                                             "chip (lpx_resident_group_r: seven 7.9 MB nodes at a time in the register files; lpx_resident_group: "
+                                             "four in LDS), so this is not HBM traffic and no fraction of the HBM peak"}
             out["bnb"] = res
         # ---- config 4 again with warm-started children (NOT the reference's re-solve) ------
         if leg("bnb_warm"):

@@ -9,8 +9,9 @@
 //   * a COLUMN of the local rows (entering column -> factors; RHS and next entering column -> the ratios the rows publish) is
 //     the RPW registers of ONE lane, which drops them into LDS;
 //   * the pivot ROW of the owner is register `rl` of every lane, `rl` workgroup-uniform but dynamic: an unrolled select chain.
-// With fewer lanes per CU a lane gets more registers: NT = 768 -> 3 waves per SIMD -> 168 VGPRs -> 28 rows of a 1282-column node per
-// workgroup -> 28 workgroups per node -> NINE config-4 nodes in flight instead of four.  Everything else -- the tagged-granule
+// With fewer lanes per CU a lane gets more registers: NT = 768 -> 3 waves per SIMD -> 168 VGPRs, of which the loop itself needs ~100:
+// 22 rows of a 1282-column node per workgroup -> 35 workgroups per node -> SEVEN config-4 nodes in flight instead of four (measured:
+// 22 rows 877 nodes/s, 26 rows / 8 nodes 802, 28 rows / 9 nodes 729 -- beyond 22 the tile spills into scratch on the critical path).  Everything else -- the tagged-granule
 // exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
 // lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
 // the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB.
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 for (int i = 1; i < RPW; ++i) if (i == rl) v = reg[i];
                 *reinterpret_cast<double2*>(rowbuf + jt) = v;
             }
-            __syncthreads();
+            rs_barrier_lds();                   // LDS only: a full barrier would also wait for the lookahead's write-through stores
             if (phase == 1) {                                                   // entering column of the dual loop, :79-91
                 if ((t >> 6) == 0) {
                     const int win = wave_hysteresis_argmin<DualColRatio, true, 4>(rhsc, N.tol_dual, DualColRatio{rowbuf, obj, eps});
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (fn_col == q) { if (t < RPW) fac[t] = fn[t]; }                       // the lookahead of the last round already formed this column
         else column_out(q, fac);
         if (t == NT - 1) fac[RPW] = obj[q];
-        __syncthreads();
+        rs_barrier_lds();
         const double fobj = fac[RPW];
         const int skip = (w == owner) ? rl : -1;
         MinIdx best; best.v = -eps; best.i = INT_MAX;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
             if (qc >= 0) column_out(qc, ca);                                    // column qc as it stands BEFORE this pivot's update
         }
-        __syncthreads();
+        rs_barrier_lds();
         fn_col = -1;
         if (look) {
             if (t < nloc) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 for (int i = 0; i < RPW; ++i) if (i == skip) reg[i] = v;
             }
         }
-        __syncthreads();                        // fac / ca / cr / prow / rowbuf are rewritten by the next round
+        rs_barrier_lds();                       // fac / ca / cr / prow / rowbuf are rewritten by the next round
         RR_T(5);
     }
 
