@@ -16,7 +16,10 @@ PEAK = 8000.0
 
 def k(prefix, grid=None):
     """the (kernel, grid) group with the most live calls whose name contains `prefix` (and whose key contains `grid`)"""
-    hit = [(n, v) for n, v in ks.items() if prefix in n.split("@")[0] and (grid is None or f"@grid{grid}" in n)]
+    # a trailing "<" in `prefix` = the kernel's name ends there (lpx_resident_group< does not match lpx_resident_group_r)
+    exact = prefix.endswith("<")
+    pre = prefix.rstrip("<")
+    hit = [(n, v) for n, v in ks.items() if (n.split("@")[0].endswith(pre) if exact else pre in n.split("@")[0]) and (grid is None or f"@grid{grid}" in n)]
     return max(hit, key=lambda nv: nv[1]["live_calls"]) if hit else (None, None)
 
 
@@ -53,7 +56,8 @@ row("K4f primal step, headline LP 4097x12289", "lpx_pivot_fused", 16.0 * R * C, 
 row("K4 in-place update, north-star 4096x8192", "lpx_update_mb", 16.0 * 4096 * 8192, grid=2097152)
 row("K4f primal step, config 2 (25 MB, cache resident)", "lpx_pivot_fused_c", 16.0 * 1025 * 3073)
 row("K0 resident primal loop, config 2 (one launch per solve)", "lpx_resident_primal", note="latency bound: two cross-CU exchanges per pivot, tableau in LDS")
-row("K0b resident group, config 4 cold (4 nodes x 60 workgroups, 96-pivot launches)", "lpx_resident_group", grid="61440x4", note="latency bound (9.3 us per pivot step of four nodes)")
+row("K0r register-resident group, config 4 cold (7 nodes x 35 workgroups x 768 lanes, 96-pivot launches)", "lpx_resident_group_r", note="latency bound (mean / 96 = us per pivot step of seven nodes)")
+row("K0b LDS-resident group (root LPs, small nodes)", "lpx_resident_group<", note="latency bound")
 row("K4g group step, warm config 4 (64-slot grid; live slots vary)", "lpx_group_fused", grid="12058624x1", note="two batches' windows overlap on the device here: durations are not additive -- the kernel by itself is the line under the table")
 row("K5 rv_price, config 3", "rv_price", 8.0 * 4096 * 8192)
 row("K6+K7 rv_upd_ftran, config 3", "rv_upd_ftran", 16.0 * 4096 * 4096)
