@@ -667,7 +667,7 @@ def main():
                                   "rv_price": rv_kernel("rv_price", kp["rv_price"], 8.0 * 4096 * 8192),
                                   "rv_upd_ftran": dict(rv_kernel("rv_upd_ftran", kp["rv_upd_ftran"], 16.0 * 4096 * 4096),
                                                        note="W (134 MB) is at home in the Infinity Cache: part of this rate is cache residency"),
-                                  "rv_pick": {"bound": "latency (one workgroup: reduces the 2048 pricing candidates, copies the entering column)",
+                                  "rv_pick": {"bound": "latency (one workgroup: reduces the 2048 pricing candidates; rv_upd_ftran reads the entering column in place)",
                                               "avg_kernel_us": kp["rv_pick"]},
                                   "rv_select2": {"bound": "latency (one workgroup: ratio test with the 1e-12 hysteresis, pivot row, (pi, z) row, bookkeeping)",
                                                  "avg_kernel_us": kp["rv_select2"]},

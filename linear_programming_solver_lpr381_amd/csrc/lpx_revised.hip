@@ -323,7 +323,7 @@ __global__ __launch_bounds__(RVF_NT) void rv_price(RvParams P)
     }
 }
 
-// entering variable from the workgroup candidates (:76-92), dense copy of its column (:95), objective-row factor
+// entering variable from the workgroup candidates (:76-92), objective-row factor
 __global__ __launch_bounds__(RV_NT) void rv_pick(RvParams P)
 {
     __shared__ double s_v[RV_NW];
@@ -352,9 +352,7 @@ __global__ __launch_bounds__(RV_NT) void rv_pick(RvParams P)
         if (t == 0) { st->status = LPX_OPTIMAL; st->r = -1; st->q = -1; }
         return;
     }
-    for (int k = t; k < P.ldw; k += RV_NT)              // aq has ldw entries; zero from m on
-        P.aq[k] = (k >= P.m) ? 0.0 : ((q < P.n) ? P.AT[(size_t)q * P.ldat + k] : ((k == q - P.n) ? 1.0 : 0.0));
-    if (t == 0) { st->q = q; P.fac[P.m] = -w.v; }       // pi.a_q - c_q = -(reduced cost)
+    if (t == 0) { st->q = q; P.fac[P.m] = -w.v; }       // pi.a_q - c_q = -(reduced cost); a_q itself (:95) is read in place by rv_upd_ftran
 }
 
 // d = B^-1 a_q fused with the pending rank-1 update of the previous pivot (see the section comment).
@@ -371,11 +369,17 @@ __global__ __launch_bounds__(RVF_NT) void rv_upd_ftran(RvParams P)
     const int rp = st->pad[3];
     constexpr int cover = RVF_NW * RVF_PER * 128;       // >= m (launcher); columns [cover, ldw) are the tail below
     rv_d2 a[RVF_PER], p[RVF_PER];
+    // a_q is read where it lies: row q of A^T, or the unit vector of a slack column (r03: rv_pick no longer copies it)
+    const int q = st->q;
+    const double* __restrict__ atq = (q < P.n) ? P.AT + (size_t)q * P.ldat : nullptr;
 #pragma unroll
     for (int u = 0; u < RVF_PER; ++u) {
         const int k = (wave + u * RVF_NW) * 128 + lane * 2;
         a[u] = rv_d2{0.0, 0.0}; p[u] = rv_d2{0.0, 0.0};
-        if (k < ldw) a[u] = *reinterpret_cast<const rv_d2*>(P.aq + k);            // a_q is zero from m on (rv_pick): column m (x_B) stays out of the dot
+        if (k < m) {                                                    // a_q is zero from m on: column m (x_B) stays out of the dot
+            if (atq) { a[u].x = atq[k]; if (k + 1 < m) a[u].y = atq[k + 1]; }
+            else { a[u].x = (k == q - P.n) ? 1.0 : 0.0; a[u].y = (k + 1 == q - P.n) ? 1.0 : 0.0; }
+        }
         if (pending && k < ldw) p[u] = *reinterpret_cast<const rv_d2*>(P.prow + k);
     }
     for (int i = blockIdx.x; i < m; i += gridDim.x) {
