@@ -40,9 +40,10 @@ struct Cut { int var; Rel rel; double bound; };
 // LPX_BNB_TIMING=1: print where the host spends its time (diagnostic)
 struct PhaseTimer {
     double build = 0, run = 0, collect = 0, decide = 0, root = 0, total = 0, readback = 0, parking = 0; bool on = false;
+    double drained = 0, drained_at = 0, drained_max = 0; int drains = 0;   // rolling batches: time with no window enqueued (the device idles once it has drained)
     PhaseTimer() { const char* e = std::getenv("LPX_BNB_TIMING"); on = e && e[0] == '1'; }
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] root %.1f ms, build %.1f ms, run %.1f ms, collect %.1f ms (read-back %.1f, parking %.1f), decide %.1f ms, whole solves %.1f ms\n", root, build, run, collect, readback, parking, decide, total); }
+    ~PhaseTimer() { if (on) std::fprintf(stderr, "[lpx bnb] root %.1f ms, build %.1f ms, run %.1f ms, collect %.1f ms (read-back %.1f, parking %.1f), decide %.1f ms, whole solves %.1f ms; no window in flight %d times, %.1f ms (longest %.1f)\n", root, build, run, collect, readback, parking, decide, total, drains, drained, drained_max); }
 };
 static PhaseTimer g_pt;
 
@@ -159,7 +160,7 @@ struct Ctx {
     }
     // resident root templates: the prepared root tableau as the primal / dual path builds it
     lpx_tableau* root_tpl[2] = {nullptr, nullptr}; int tplR[2] = {0, 0}, tplC[2] = {0, 0}; bool tpl_bad[2] = {false, false};
-    ~Ctx() { lpx_tableau_destroy(root_tpl[0]); lpx_tableau_destroy(root_tpl[1]); for (auto& kv : stores) lpx_store_destroy(kv.second); }
+    ~Ctx() { for (int w = 0; w < 2; ++w) release_exact_handle(root_tpl[w], tplR[w], tplC[w]); for (auto& kv : stores) lpx_store_destroy(kv.second); }
     void log(const std::string& s) { if (cb) cb(s + "\n", nullptr); }
 };
 
@@ -293,9 +294,9 @@ bool ensure_template(Ctx& c, bool dual)
             BuildTableauPrimal(PrepareForTableauDual(*c.root, c.opt.bnb_mode == 1), T, R, C, basis, names);
         }
     } catch (const LpxException&) { c.tpl_bad[w] = true; return false; }
-    int rc = lpx_tableau_create(R, C, &c.root_tpl[w]);
-    if (rc) throw LpxException(rc, "liblpx: " + last_error());
-    rc = lpx_tableau_upload(c.root_tpl[w], T.data(), basis.data());
+    c.root_tpl[w] = acquire_exact_handle(R, C);
+    c.tplR[w] = R; c.tplC[w] = C;
+    int rc = lpx_tableau_upload(c.root_tpl[w], T.data(), basis.data());
     if (rc) throw LpxException(rc, "liblpx: " + last_error());
     c.tplR[w] = R; c.tplC[w] = C;
     return true;
@@ -495,6 +496,10 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             const int rc = lpx_multi_run_begin(s, hs.data(), dual.data(), (int)hs.size(), &po, &dopt, steps);
             if (rc < 0) throw LpxException(rc, "liblpx: " + last_error());
             if (rc == 1) { async_ok = false; return; }               // not available: the synchronous loop below takes what is in the sets
+            if (g_pt.on && g_pt.drained_at > 0 && !sets[s ^ 1].running) {
+                const double d = PhaseTimer::now() - g_pt.drained_at;
+                g_pt.drained += d; g_pt.drains++; g_pt.drained_max = std::max(g_pt.drained_max, d);
+            }
             S.running = true;
         };
         auto land = [&](int s) {
@@ -504,6 +509,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             const int rc = lpx_multi_run_end(s, st.data(), ss.data());
             g_pt.run += PhaseTimer::now() - t0;
             S.running = false;
+            if (g_pt.on && !sets[s ^ 1].running) g_pt.drained_at = PhaseTimer::now();
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
             std::vector<NodeLP*> fin, keep; std::vector<int> fst; std::vector<lpx_stats> fss;
             for (size_t i = 0; i < S.inflight.size(); ++i) {

@@ -218,4 +218,12 @@ void BuildTableauPrimal(const LPProblem& expanded, std::vector<double>& T, int& 
 LPProblem ExpandEqualitiesToInequalities(const LPProblem& model);
 LPProblem PrepareForTableauDual(const LPProblem& original, bool fix_d1);
 
-}}  // namespace lpx::host
+// Handles of whole-model solves and of the B&B root templates, kept from one solve to the next (creating a handle costs ~4 ms of device
+// and pinned allocations, destroying it ~3 ms: two root solves and two templates were 25-30 ms of every search).  Exact shapes only --
+// these handles are never rebuilt to another size -- small tableaux only (<= 32 MB), a bounded number; everything else is created and
+// destroyed as before.  acquire: a cached handle of that shape or a new one (throws LpxException); release: back to the cache or destroyed.
+::lpx_tableau* acquire_exact_handle(int R, int C);
+void release_exact_handle(::lpx_tableau* t, int R, int C);
+
+}
+}  // namespace lpx::host

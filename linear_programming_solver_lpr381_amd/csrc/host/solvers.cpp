@@ -6,9 +6,49 @@
 #include <algorithm>
 #include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace lpx { namespace host {
+
+namespace {
+struct ExactHandleCache {
+    std::map<std::pair<int, int>, std::vector<lpx_tableau*>> free_;
+    size_t count = 0;
+    std::mutex mu;
+};
+ExactHandleCache& exact_cache() { static ExactHandleCache* c = new ExactHandleCache; return *c; }   // never destroyed: the HIP runtime may be gone at exit
+constexpr size_t kExactMax = 16;
+constexpr size_t kExactBytes = (size_t)32 << 20;
+}  // namespace
+
+lpx_tableau* acquire_exact_handle(int R, int C)
+{
+    {
+        ExactHandleCache& c = exact_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_.find({R, C});
+        if (it != c.free_.end() && !it->second.empty()) { lpx_tableau* t = it->second.back(); it->second.pop_back(); --c.count; return t; }
+    }
+    lpx_tableau* t = nullptr;
+    const int rc = lpx_tableau_create(R, C, &t);
+    if (rc) { char buf[1024]; lpx_last_error(buf, sizeof(buf)); throw LpxException(rc, std::string("liblpx: ") + buf); }
+    return t;
+}
+
+void release_exact_handle(lpx_tableau* t, int R, int C)
+{
+    if (!t) return;
+    static const bool keep = [] { const char* e = std::getenv("LPX_HANDLE_CACHE"); return !(e && e[0] == '0'); }();   // diagnostic
+    if (keep && sizeof(double) * (size_t)R * (size_t)C <= kExactBytes) {
+        ExactHandleCache& c = exact_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.count < kExactMax) { c.free_[{R, C}].push_back(t); ++c.count; return; }
+    }
+    lpx_tableau_destroy(t);
+}
 
 namespace {
 
@@ -22,9 +62,9 @@ std::string last_error()
 [[noreturn]] void throw_lib(int rc) { throw LpxException(rc, "liblpx: " + last_error()); }
 
 struct TableauHandle {
-    lpx_tableau* h = nullptr;
-    TableauHandle(int R, int C) { int rc = lpx_tableau_create(R, C, &h); if (rc) throw_lib(rc); }
-    ~TableauHandle() { lpx_tableau_destroy(h); }
+    lpx_tableau* h = nullptr; int R_, C_;
+    TableauHandle(int R, int C) : R_(R), C_(C) { h = acquire_exact_handle(R, C); }
+    ~TableauHandle() { release_exact_handle(h, R_, C_); }
     TableauHandle(const TableauHandle&) = delete;
 };
 

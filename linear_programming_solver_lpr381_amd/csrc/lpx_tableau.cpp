@@ -902,8 +902,14 @@ struct FusedGroupBuf {
     std::vector<hipEvent_t> ev;
 };
 
+extern FusedGroupBuf g_fgroups[3];
 int fused_group_reserve(FusedGroupBuf& g, int count)
 {
+    static const bool one_stream = [] { const char* e = std::getenv("LPX_ROLL_ONE_STREAM"); return e && e[0] == '1'; }();   // experiment
+    if (!g.stream && one_stream && (&g == &g_fgroups[0] || &g == &g_fgroups[1])) {
+        FusedGroupBuf& o = (&g == &g_fgroups[0]) ? g_fgroups[1] : g_fgroups[0];
+        if (o.stream) g.stream = o.stream;
+    }
     if (!g.stream) {
         // LOWEST priority: a window is a dozen chip-filling launches in a row; the small launches the host needs answered while the
         // other batch pivots (solution read-back, parking, child assembly: other streams, default priority) must get their
@@ -1074,7 +1080,7 @@ int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_
 
 // ---- the same in two halves: one window of `steps` pivots of every run of a batch, enqueued and collected separately, so that the
 //      host can work on one batch (read-back, parking, assembly of the next nodes) while the other one pivots ----
-struct FusedAsync { bool active = false; std::vector<lpx_tableau*> ts; std::vector<int> dual; double t0 = 0; long long enq = 0; };
+struct FusedAsync { bool active = false; std::vector<lpx_tableau*> ts; std::vector<int> dual; double t0 = 0; long long enq = 0; hipEvent_t done = nullptr; };
 FusedAsync g_fasync[2];
 
 }  // namespace
@@ -1113,6 +1119,8 @@ int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, 
       LPX_HIP_TRY(hipMemcpyAsync(g.comp_d, g.comp_h, sizeof(int) * (hdr + count), hipMemcpyHostToDevice, g.stream)); }
     for (int i = 0; i < steps; ++i) LPX_HIP_TRY(launch_group_fused(g.d, g.live_d, count, per_node, i & 1, live_bytes, g.stream, g.comp_d, g.cap));
     LPX_HIP_TRY(launch_group_fused_gather(g.d, count, g.hs, g.cur_h, g.stream));
+    if (!a.done) LPX_HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    LPX_HIP_TRY(hipEventRecord(a.done, g.stream));              // the two slots may share a stream: wait for THIS window, not for the stream
     a.active = true; a.ts.assign(ts, ts + count); a.dual.assign(dual, dual + count); a.t0 = t0; a.enq = steps;
     return 0;
 }
@@ -1124,7 +1132,7 @@ int lpx_multi_run_end(int slot, int* statuses, lpx_stats* stats)
     if (!a.active) { set_error("lpx_multi_run_end: no batch in flight in this slot"); return LPX_EINVAL; }
     FusedGroupBuf& g = g_fgroups[slot];
     a.active = false;
-    LPX_HIP_TRY(hipStreamSynchronize(g.stream));
+    LPX_HIP_TRY(hipEventSynchronize(a.done));
     fused_finish(g, a.ts.data(), a.dual.data(), (int)a.ts.size(), true, now_ms() - a.t0, a.enq, statuses, stats, 0.0, 0);
     return 0;
 }
