@@ -246,10 +246,27 @@ def main():
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(L.comm.unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            L.comm.init(rank, world, bytes(idt.cpu().numpy().tobytes()))
-            chk = L.comm.allreduce_max(np.array([float(rank), -float(rank)]))
-            assert chk.tolist() == [float(world - 1), 0.0], f"lpx_comm all-reduce(max) returned {chk.tolist()}"
-            engine_comm = "lpx_comm"
+            comm_err = None
+            try:
+                L.comm.init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+                chk = L.comm.allreduce_max(np.array([float(rank), -float(rank)]))
+                if chk.tolist() != [float(world - 1), 0.0]:
+                    comm_err = f"lpx_comm all-reduce(max) returned {chk.tolist()}"
+            except Exception as e:                         # noqa: BLE001 -- any failure here must not cost the run its numbers
+                comm_err = f"{type(e).__name__}: {e}"
+            # every rank takes the same path: one torch all-reduce says whether anybody's communicator failed
+            okt = torch.tensor([0.0 if comm_err else 1.0], device="cuda")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if okt.item() >= 1.0:
+                engine_comm = "lpx_comm"
+            else:
+                # the searches then exchange their bound through the host callback over torch.distributed (same RCCL, torch's
+                # communicator); the line says so (`engine_collective`)
+                print(f"[bench] rank {rank}: liblpx's communicator is not used ({comm_err or 'a peer failed'}); "
+                      "falling back to the torch.distributed callback", file=sys.stderr, flush=True)
+                if not comm_err:
+                    L.comm.destroy()
+                engine_comm = None
 
     def barrier():
         if use_dist:

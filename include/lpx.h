@@ -206,12 +206,13 @@ int lpx_multi_run(lpx_tableau** ts, const int* dual, int count, const lpx_run_op
 int lpx_multi_run_some(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
                        const lpx_run_opts* dual_opts, int* statuses, lpx_stats* stats /* [count] or NULL */, int min_active);
 
-/* The same in two halves, for hosts that keep TWO rolling batches (slot 0 and 1) so that one pivots while the other is read
- * back, decided on and refilled: _begin enqueues `steps` pivots (rounded up to even) of every run of the batch -- fresh
+/* The same in two halves, for hosts that keep TWO OR MORE rolling batches (slots 0 .. LPX_ASYNC_SLOTS - 1) so that one pivots while
+ * another is read back, decided on and refilled: _begin enqueues `steps` pivots (rounded up to even) of every run of the batch -- fresh
  * tableaux and runs a previous window left as LPX_RUNNING alike -- on the slot's own stream and returns at once; _end waits for
  * that window and reports as lpx_multi_run_some does (LPX_RUNNING = unfinished, hand it in again).  Between the two calls the
  * batch's handles must not be touched.  _begin returns 1 (nothing enqueued) when the one-launch-per-step kernels cannot take
  * the batch (a second tableau buffer did not fit, profile mode): use lpx_multi_run_some then. */
+#define LPX_ASYNC_SLOTS 4   /* slot = 0 .. LPX_ASYNC_SLOTS - 1 */
 int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* primal_opts,
                         const lpx_run_opts* dual_opts, int steps);
 int lpx_multi_run_end(int slot, int* statuses, lpx_stats* stats /* [count of the _begin] or NULL */);

@@ -482,7 +482,9 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         size_t next = 0;
         const int steps = dopt.batch > 0 ? dopt.batch : 16;
         struct Set { std::vector<NodeLP*> inflight; bool running = false; };
-        Set sets[2];
+        static const int NS = [] { const char* e = std::getenv("LPX_ROLL_SETS"); const int v = e ? std::atoi(e) : 0; return v >= 2 && v <= LPX_ASYNC_SLOTS ? v : 2; }();
+        Set sets[LPX_ASYNC_SLOTS];
+        auto others_running = [&](int s) { for (int k = 0; k < NS; ++k) if (k != s && sets[k].running) return true; return false; };
         bool async_ok = pipelined;
         auto launch = [&](int s) {
             Set& S = sets[s];
@@ -496,7 +498,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             const int rc = lpx_multi_run_begin(s, hs.data(), dual.data(), (int)hs.size(), &po, &dopt, steps);
             if (rc < 0) throw LpxException(rc, "liblpx: " + last_error());
             if (rc == 1) { async_ok = false; return; }               // not available: the synchronous loop below takes what is in the sets
-            if (g_pt.on && g_pt.drained_at > 0 && !sets[s ^ 1].running) {
+            if (g_pt.on && g_pt.drained_at > 0 && !others_running(s)) {
                 const double d = PhaseTimer::now() - g_pt.drained_at;
                 g_pt.drained += d; g_pt.drains++; g_pt.drained_max = std::max(g_pt.drained_max, d);
             }
@@ -509,7 +511,7 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
             const int rc = lpx_multi_run_end(s, st.data(), ss.data());
             g_pt.run += PhaseTimer::now() - t0;
             S.running = false;
-            if (g_pt.on && !sets[s ^ 1].running) g_pt.drained_at = PhaseTimer::now();
+            if (g_pt.on && !others_running(s)) g_pt.drained_at = PhaseTimer::now();
             if (rc) throw LpxException(rc, "liblpx: " + last_error());
             std::vector<NodeLP*> fin, keep; std::vector<int> fst; std::vector<lpx_stats> fss;
             for (size_t i = 0; i < S.inflight.size(); ++i) {
@@ -530,21 +532,20 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
         };
         if (async_ok) {
             try {
-                launch(0);
-                if (async_ok) launch(1);
-                while (async_ok && (sets[0].running || sets[1].running))
-                    for (int s = 0; s < 2 && async_ok; ++s) {
+                for (int s = 0; s < NS && async_ok; ++s) launch(s);
+                while (async_ok && others_running(-1))
+                    for (int s = 0; s < NS && async_ok; ++s) {
                         if (!sets[s].running) continue;
                         land(s);
                         launch(s);
                     }
             } catch (...) {
                 // a window may still be in flight in the other slot: wait for it before the handles go back to the pool
-                for (int s = 0; s < 2; ++s) if (sets[s].running) { std::vector<int> st(sets[s].inflight.size()); lpx_multi_run_end(s, st.data(), nullptr); sets[s].running = false; }
+                for (int s = 0; s < NS; ++s) if (sets[s].running) { std::vector<int> st(sets[s].inflight.size()); lpx_multi_run_end(s, st.data(), nullptr); sets[s].running = false; }
                 throw;
             }
             if (async_ok) return;
-            for (int s = 0; s < 2; ++s) if (sets[s].running) land(s);
+            for (int s = 0; s < NS; ++s) if (sets[s].running) land(s);
         }
         // synchronous form (one batch; also what is left when the two-slot path was not available)
         std::vector<NodeLP*> inflight;

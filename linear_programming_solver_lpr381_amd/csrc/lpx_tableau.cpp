@@ -902,14 +902,13 @@ struct FusedGroupBuf {
     std::vector<hipEvent_t> ev;
 };
 
-extern FusedGroupBuf g_fgroups[3];
+static constexpr int kAsyncSlots = 4;           // rolling batches a host may keep in flight (lpx_multi_run_begin / _end)
+extern FusedGroupBuf g_fgroups[kAsyncSlots + 1];
 int fused_group_reserve(FusedGroupBuf& g, int count)
 {
     static const bool one_stream = [] { const char* e = std::getenv("LPX_ROLL_ONE_STREAM"); return e && e[0] == '1'; }();   // experiment
-    if (!g.stream && one_stream && (&g == &g_fgroups[0] || &g == &g_fgroups[1])) {
-        FusedGroupBuf& o = (&g == &g_fgroups[0]) ? g_fgroups[1] : g_fgroups[0];
-        if (o.stream) g.stream = o.stream;
-    }
+    if (!g.stream && one_stream && &g >= &g_fgroups[0] && &g < &g_fgroups[kAsyncSlots])
+        for (int k = 0; k < kAsyncSlots && !g.stream; ++k) if (g_fgroups[k].stream) g.stream = g_fgroups[k].stream;
     if (!g.stream) {
         // LOWEST priority: a window is a dozen chip-filling launches in a row; the small launches the host needs answered while the
         // other batch pivots (solution read-back, parking, child assembly: other streams, default priority) must get their
@@ -944,7 +943,7 @@ int fused_group_reserve(FusedGroupBuf& g, int count)
     return 0;
 }
 
-FusedGroupBuf g_fgroups[3];          // [0], [1]: the two asynchronous batches (lpx_multi_run_begin / _end), [2]: the synchronous runs
+FusedGroupBuf g_fgroups[kAsyncSlots + 1];   // [0 .. kAsyncSlots): the asynchronous batches (lpx_multi_run_begin / _end), [kAsyncSlots]: the synchronous runs
 
 // parameter records, initial states and the init launch of a group; returns LPX_RESIDENT_RETRY when the group cannot take the
 // fused path (nothing has been touched then)
@@ -1025,7 +1024,7 @@ void fused_finish(FusedGroupBuf& g, lpx_tableau** ts, const int* dual, int count
 int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts,
                     int* statuses, lpx_stats* stats, const DevState* inits, int min_active)
 {
-    FusedGroupBuf& g = g_fgroups[2];
+    FusedGroupBuf& g = g_fgroups[kAsyncSlots];
     const double t0 = now_ms();
     int per_node = 1, batch = 64; long long budget = 0;
     { const int rc = fused_prepare(g, ts, dual, count, popts, dopts, inits, &per_node, &batch, &budget); if (rc) return rc; }
@@ -1081,7 +1080,7 @@ int multi_run_fused(lpx_tableau** ts, const int* dual, int count, const lpx_run_
 // ---- the same in two halves: one window of `steps` pivots of every run of a batch, enqueued and collected separately, so that the
 //      host can work on one batch (read-back, parking, assembly of the next nodes) while the other one pivots ----
 struct FusedAsync { bool active = false; std::vector<lpx_tableau*> ts; std::vector<int> dual; double t0 = 0; long long enq = 0; hipEvent_t done = nullptr; };
-FusedAsync g_fasync[2];
+FusedAsync g_fasync[kAsyncSlots];
 
 }  // namespace
 
@@ -1089,7 +1088,7 @@ extern "C" {
 
 int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, const lpx_run_opts* popts, const lpx_run_opts* dopts, int steps)
 {
-    if (slot < 0 || slot > 1 || !ts || !dual || count < 1 || steps < 1) { set_error("lpx_multi_run_begin: bad argument"); return LPX_EINVAL; }
+    if (slot < 0 || slot >= kAsyncSlots || !ts || !dual || count < 1 || steps < 1) { set_error("lpx_multi_run_begin: bad argument"); return LPX_EINVAL; }
     FusedAsync& a = g_fasync[slot];
     if (a.active) { set_error("lpx_multi_run_begin: this slot has a batch in flight (lpx_multi_run_end first)"); return LPX_EINVAL; }
     lpx_run_opts pd, dd;
@@ -1127,7 +1126,7 @@ int lpx_multi_run_begin(int slot, lpx_tableau** ts, const int* dual, int count, 
 
 int lpx_multi_run_end(int slot, int* statuses, lpx_stats* stats)
 {
-    if (slot < 0 || slot > 1 || !statuses) { set_error("lpx_multi_run_end: bad argument"); return LPX_EINVAL; }
+    if (slot < 0 || slot >= kAsyncSlots || !statuses) { set_error("lpx_multi_run_end: bad argument"); return LPX_EINVAL; }
     FusedAsync& a = g_fasync[slot];
     if (!a.active) { set_error("lpx_multi_run_end: no batch in flight in this slot"); return LPX_EINVAL; }
     FusedGroupBuf& g = g_fgroups[slot];
