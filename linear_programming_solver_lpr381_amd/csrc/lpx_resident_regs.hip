@@ -9,9 +9,13 @@
 //   * a COLUMN of the local rows (entering column -> factors; RHS and next entering column -> the ratios the rows publish) is
 //     the RPW registers of ONE lane, which drops them into LDS;
 //   * the pivot ROW of the owner is register `rl` of every lane, `rl` workgroup-uniform but dynamic: an unrolled select chain.
-// With fewer lanes per CU a lane gets more registers: NT = 768 -> 3 waves per SIMD -> 168 VGPRs, of which the loop itself needs ~100:
-// 22 rows of a 1282-column node per workgroup -> 35 workgroups per node -> SEVEN config-4 nodes in flight instead of four (measured:
-// 22 rows 877 nodes/s, 26 rows / 8 nodes 802, 28 rows / 9 nodes 729 -- beyond 22 the tile spills into scratch on the critical path).  Everything else -- the tagged-granule
+// With fewer lanes per CU a lane gets more registers, and fewer lanes pay the loop's own ~85 registers:
+//   NT = 768, two columns per lane, 3 waves per SIMD (168 VGPRs): 22 rows of a 1282-column node per workgroup -> 35 workgroups per
+//     node -> SEVEN config-4 nodes in flight instead of the LDS form's four (845-880 nodes/s; 26 rows / 8 nodes 802, 28 rows / 9 nodes
+//     729: beyond 22 rows that tile spills into scratch on the critical path);
+//   NT = 512, THREE columns per lane, 2 waves per SIMD (256 VGPRs, 2 spilled): 28 rows -> 28 workgroups per node -> NINE nodes in
+//     flight: 964 nodes/s on the box where the first form gives 845 (31 rows / ten nodes spill 40 registers: 805).
+// Everything else -- the tagged-granule
 // exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
 // lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
 // the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB.
@@ -75,8 +79,13 @@ __device__ __forceinline__ int rr_first_min_below(const double* v, int L, double
     return m.i == INT_MAX ? -1 : m.i;
 }
 
-// WPE = waves per SIMD the kernel is compiled for (NT / 256): sets the register budget
-template <int NT, int RPW, int WPE>
+// width of the register tile and of the LDS rows: the first multiple of 2 and of kc at or above C
+__host__ __device__ __forceinline__ int rr_tile_width(int C, int kc) { const int u = (kc & 1) ? 2 * kc : kc; return (C + u - 1) / u * u; }
+
+// WPE = waves per SIMD the kernel is compiled for (NT / 256): sets the register budget.  KC = columns per lane: 2 for tableaux up to
+// 2 NT columns; 3 lets 512 lanes (two waves per SIMD, 256 VGPRs each) carry a 1536-column node -- fewer lanes pay the loop's own ~80
+// registers, so a CU holds 28 rows of a config-4 node instead of 22 and the chip NINE nodes instead of seven.
+template <int NT, int RPW, int WPE, int KC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void lpx_resident_group_r(ResGroupParamsR GP)
 {
     extern __shared__ __align__(16) double rr_lds[];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const int nloc = max(0, min(rpw, m - row0));
     const int mp = (m + 1) & ~1;
     const int gld = P.ld;
-    const int ld = (C + 1) & ~1;                // width of the register tile: NT >= ld / 2 (host)
+    const int ld = rr_tile_width(C, KC);        // width of the register tile (a multiple of 2 and of KC): NT >= ld / KC, ld <= gld (host)
     double* obj = rr_lds;                       // [ld]
     double* prow = obj + ld;                    // [ld]
     double* rowbuf = prow + ld;                 // [ld]   the owner's pivot row as it stands (before the division)
@@ -110,13 +119,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     double* cr = ca + RPW;                      // [RPW]  RHS column of the local rows, kept current from round to round (as the tile's own)
     double* fn = cr + RPW;                      // [RPW]  column qc as the lookahead left it = the next pivot's factors when it enters
 
-    const int jt = 2 * t;                       // this lane's column pair
+    const int jt = KC * t;                      // this lane's columns: jt .. jt + KC - 1
     const bool mine = jt < ld;
-    double2 reg[RPW];
+    double reg[RPW][KC];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        reg[i] = make_double2(0.0, 0.0);
-        if (i < nloc && mine) reg[i] = *reinterpret_cast<const double2*>(P.T + (size_t)(row0 + i) * gld + jt);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) reg[i][c] = 0.0;
+        if (i < nloc && mine) {
+            const double* src = P.T + (size_t)(row0 + i) * gld + jt;
+            if (KC == 2) { const double2 v = *reinterpret_cast<const double2*>(src); reg[i][0] = v.x; reg[i][KC - 1] = v.y; }
+            else {
+#pragma unroll
+                for (int c = 0; c < KC; ++c) reg[i][c] = src[c];
+            }
+        }
     }
     {
         const double* src = P.T + (size_t)m * gld;
@@ -129,13 +146,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
     // column c of the local rows -> dst[0..RPW): the registers of the one lane that owns it
     auto column_out = [&](int c, double* dst) __attribute__((always_inline)) {
-        if (t == (c >> 1)) {
-            // the odd / even half by bit masks: written as `odd ? reg[i].y : reg[i].x` the compiler turns the select of two values into a
+        if (t == c / KC) {
+            // the lane's column by bit masks: written as `odd ? reg[i].y : reg[i].x` the compiler turns the select of two values into a
             // select of two ADDRESSES and moves the whole register tile into scratch memory (480 bytes per lane, 4.6x slower per step)
-            const long long mk = -(long long)(c & 1);
+            const int cc = c - KC * t;
+            long long mk[KC];
 #pragma unroll
-            for (int i = 0; i < RPW; ++i)
-                dst[i] = __longlong_as_double((__double_as_longlong(reg[i].x) & ~mk) | (__double_as_longlong(reg[i].y) & mk));
+            for (int u = 0; u < KC; ++u) mk[u] = -(long long)(cc == u);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                long long b = 0;
+#pragma unroll
+                for (int u = 0; u < KC; ++u) b |= __double_as_longlong(reg[i][u]) & mk[u];
+                dst[i] = __longlong_as_double(b);
+            }
         }
     };
 
@@ -215,10 +239,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (w == owner) {
             // the pivot row out of the registers: register `rl` of every lane (rl is uniform, the chain is unrolled)
             if (mine) {
-                double2 v = reg[0];
+                double v[KC];
 #pragma unroll
-                for (int i = 1; i < RPW; ++i) if (i == rl) v = reg[i];
-                *reinterpret_cast<double2*>(rowbuf + jt) = v;
+                for (int c = 0; c < KC; ++c) v[c] = reg[0][c];
+#pragma unroll
+                for (int i = 1; i < RPW; ++i)
+                    if (i == rl) {
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) v[c] = reg[i][c];
+                    }
+#pragma unroll
+                for (int c = 0; c < KC; ++c) rowbuf[jt + c] = v[c];
             }
             rs_barrier_lds();                   // LDS only: a full barrier would also wait for the lookahead's write-through stores
             if (phase == 1) {                                                   // entering column of the dual loop, :79-91
@@ -336,18 +367,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         //      dummies nobody reads, and the owner's pivot row -- which the update must leave alone (:252) -- is put back afterwards
         //      from the normalised row (a predicate per row would cost two scalar mask registers each, hoisted out of the round loop)
         if (mine) {
-            const double2 p = *reinterpret_cast<const double2*>(prow + jt);
+            double p[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) p[c] = prow[jt + c];
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const double f = fac[i];
-                double prod = f * p.x; reg[i].x = reg[i].x - prod;
-                prod = f * p.y; reg[i].y = reg[i].y - prod;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) { const double prod = f * p[c]; reg[i][c] = reg[i][c] - prod; }
             }
             if (skip >= 0) {                                                    // row r of the owner = the normalised pivot row, :249-250
-                double2 v = p;
-                if (jt + 1 >= C) v.y = rowbuf[jt + 1 < ld ? jt + 1 : jt];       // the padding column keeps what it held
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) if (i == skip) reg[i] = v;
+                for (int c = 0; c < KC; ++c) if (jt + c >= C) p[c] = rowbuf[jt + c];   // the padding columns keep what they held
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+                    if (i == skip) {
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) reg[i][c] = p[c];
+                    }
             }
         }
         rs_barrier_lds();                       // fac / ca / cr / prow / rowbuf are rewritten by the next round
@@ -361,7 +398,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (mine) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
-            if (i < nloc) *reinterpret_cast<double2*>(P.T + (size_t)(row0 + i) * gld + jt) = reg[i];
+            if (i < nloc) {
+                double* dst = P.T + (size_t)(row0 + i) * gld + jt;
+                if (KC == 2) *reinterpret_cast<double2*>(dst) = make_double2(reg[i][0], reg[i][KC - 1]);
+                else {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) dst[c] = reg[i][c];
+                }
+            }
     }
     if (w == 0) {
         double* dst = P.T + (size_t)m * gld;
@@ -382,41 +426,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-// shapes the register kernel is instantiated for: (lanes, rows per workgroup)
-static constexpr int RR_NT_A = 768, RR_RPW_A = 22;     // tableaux up to 1536 columns: config 4 and its branching levels
+// shapes the register kernel is instantiated for: (lanes, rows per workgroup, columns per lane)
+static constexpr int RR_NT_A = 768, RR_RPW_A = 22;     // tableaux up to 1536 columns, two columns per lane (r03's first form: seven config-4 nodes)
 static constexpr int RR_NT_B = 512, RR_RPW_B = 48;     // up to 1024 columns
+static constexpr int RR_NT_C = 512, RR_RPW_C = 28;     // up to 1536 columns, THREE columns per lane: nine config-4 nodes
 
-size_t resident_regs_lds(int R, int C, int rpw_max)
+static int rr_kc(int cfg) { return cfg == 3 ? 3 : 2; }
+
+size_t resident_regs_lds(int R, int C, int rpw_max, int cfg)
 {
-    const int m = R - 1, ld = (C + 1) & ~1;
+    const int m = R - 1, ld = rr_tile_width(C, rr_kc(cfg));
     return sizeof(double) * ((size_t)3 * ld + (size_t)((m + 1) & ~1) + (size_t)4 * rpw_max + 2);
 }
 
-// 0 = this group does not fit the register kernel; else the workgroup size, with *rpw_max the rows a workgroup can hold
-int resident_regs_shape(int maxC, int* rpw_max)
+// 0 = this group does not fit the register kernel; else the configuration (1 = B, 2 = A, 3 = C), with *rpw_max the rows a
+// workgroup can hold.  min_ld = the smallest row pitch of the group: the tile must not be wider than a row in memory.
+int resident_regs_shape(int maxC, int min_ld, int* rpw_max)
 {
-    const int ld = (maxC + 1) & ~1;
-    if (ld <= 2 * RR_NT_B) { *rpw_max = RR_RPW_B; return RR_NT_B; }
-    if (ld <= 2 * RR_NT_A) { *rpw_max = RR_RPW_A; return RR_NT_A; }
+    static const int wide = [] { const char* e = std::getenv("LPX_RESIDENT_REGS_KC"); return e ? std::atoi(e) : 3; }();   // diagnostic: 2 = the two-column form for wide nodes
+    if (rr_tile_width(maxC, 2) <= 2 * RR_NT_B && rr_tile_width(maxC, 2) <= min_ld) { *rpw_max = RR_RPW_B; return 1; }
+    if (wide == 3 && rr_tile_width(maxC, 3) <= 3 * RR_NT_C && rr_tile_width(maxC, 3) <= min_ld) { *rpw_max = RR_RPW_C; return 3; }
+    if (rr_tile_width(maxC, 2) <= 2 * RR_NT_A && rr_tile_width(maxC, 2) <= min_ld) { *rpw_max = RR_RPW_A; return 2; }
     return 0;
 }
 
 hipError_t resident_regs_init()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2>),
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     return e;
 }
 
-hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int nt, size_t lds, int chunk, hipStream_t s)
+hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, size_t lds, int chunk, hipStream_t s)
 {
     ResGroupParamsR p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
     static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
     p.mute = mute;
-    if (nt == RR_NT_A) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);
-    else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2>), dim3(grid, nodes), dim3(RR_NT_B), lds, s, p);
+    if (cfg == 2) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);
+    else if (cfg == 3) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3>), dim3(grid, nodes), dim3(RR_NT_C), lds, s, p);
+    else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2>), dim3(grid, nodes), dim3(RR_NT_B), lds, s, p);
     return hipGetLastError();
 }
 

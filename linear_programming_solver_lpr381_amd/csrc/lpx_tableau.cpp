@@ -573,16 +573,16 @@ static int resident_regs_plan(lpx_tableau** ts, int count, int cus, int* grid, s
 {
     static const bool enabled = [] { const char* e = std::getenv("LPX_RESIDENT_REGS"); return !(e && e[0] == '0'); }();
     if (!enabled) return 0;
-    int maxC = 2, mmax = 1, mmin = 1 << 30;
-    for (int i = 0; i < count; ++i) { maxC = std::max(maxC, ts[i]->C); mmax = std::max(mmax, ts[i]->R - 1); mmin = std::min(mmin, ts[i]->R - 1); }
+    int maxC = 2, mmax = 1, mmin = 1 << 30, min_ld = 1 << 30;
+    for (int i = 0; i < count; ++i) { maxC = std::max(maxC, ts[i]->C); mmax = std::max(mmax, ts[i]->R - 1); mmin = std::min(mmin, ts[i]->R - 1); min_ld = std::min(min_ld, ts[i]->ld); }
     int rpw_max = 0;
-    const int n = resident_regs_shape(maxC, &rpw_max);
+    const int n = resident_regs_shape(maxC, min_ld, &rpw_max);       // the kernel configuration
     if (!n) return 0;
     int g = (mmax + rpw_max - 1) / rpw_max;                 // workgroups per node: every node's rows per workgroup <= rpw_max
     if (g > mmin || g > cus) return 0;
     { const int rpw = (mmax + g - 1) / g; g = (mmax + rpw - 1) / rpw; }          // no idle workgroups for the tallest node
     size_t need = 0;
-    for (int i = 0; i < count; ++i) need = std::max(need, resident_regs_lds(ts[i]->R, ts[i]->C, rpw_max));
+    for (int i = 0; i < count; ++i) need = std::max(need, resident_regs_lds(ts[i]->R, ts[i]->C, rpw_max, n));
     if (need > (size_t)96 * 1024) return 0;
     *grid = g; *lds = need; *nt = n;
     return cus / g;
@@ -643,7 +643,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
                        DevState* resume = nullptr)
 {
     ResGroupBuf& g = g_resgroup;
-    const int plan_nt = tl_plan_nt;             // 0: rows in LDS; else lanes per workgroup of the register-resident kernel
+    const int plan_nt = tl_plan_nt;             // 0: rows in LDS; else the configuration of the register-resident kernel
     if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (g.cap < count) {
         hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
