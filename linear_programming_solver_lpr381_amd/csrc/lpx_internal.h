@@ -132,9 +132,9 @@ size_t resident_group_lds(int R, int C, int ld, int grid);
 hipError_t resident_group_init();
 // register-resident variant (lpx_resident_regs.hip): node rows in VGPRs, more nodes per launch
 hipError_t resident_regs_init();
-int resident_regs_shape(int maxC, int min_ld, int* rpw_max); // 0 = does not fit; else the kernel configuration (1, 2, 3)
-size_t resident_regs_lds(int R, int C, int rpw_max, int cfg);
-hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, size_t lds, int chunk, hipStream_t s);
+int resident_regs_shape(int maxC, int min_ld, int mmax, int* rpw_max);   // 0 = does not fit; else the kernel configuration (1, 2, 3)
+size_t resident_regs_lds(int R, int C, int rt, int cfg);
+hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, int rt, size_t lds, int chunk, hipStream_t s);
 hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s);
 // resident primal loop (lpx_resident.hip)
 hipError_t resident_init();

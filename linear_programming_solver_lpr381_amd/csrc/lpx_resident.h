@@ -80,6 +80,30 @@ __device__ __forceinline__ bool rs_gather2(const u64* g, int i0, int i1, int cou
     return pending == 0;
 }
 
+// Three per round: 512 lanes cover a 1536-entry row in one round trip (the three-column form of the register-resident kernel).
+__device__ __forceinline__ bool rs_gather3(const u64* g, int i0, int i1, int i2, int count, unsigned gen, double* out,
+                                           unsigned max_spin = RS_SPIN_MAX, unsigned* pend = nullptr)
+{
+    unsigned pending = pend ? *pend : (1u << count) - 1u;
+    const u64* p0 = g + 2 * (size_t)i0;
+    const u64* p1 = g + 2 * (size_t)(count > 1 ? i1 : i0);
+    const u64* p2 = g + 2 * (size_t)(count > 2 ? i2 : i0);
+    for (unsigned spin = 0; spin < max_spin && pending; ++spin) {
+        rs_u4 w0, w1, w2;
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                     "global_load_dwordx4 %1, %4, off sc1\n\t"
+                     "global_load_dwordx4 %2, %5, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+        if ((pending & 1u) && w0.y == gen && w0.w == gen) { out[0] = __longlong_as_double((long long)(((u64)w0.z << 32) | (u64)w0.x)); pending &= ~1u; }
+        if ((pending & 2u) && w1.y == gen && w1.w == gen) { out[1] = __longlong_as_double((long long)(((u64)w1.z << 32) | (u64)w1.x)); pending &= ~2u; }
+        if ((pending & 4u) && w2.y == gen && w2.w == gen) { out[2] = __longlong_as_double((long long)(((u64)w2.z << 32) | (u64)w2.x)); pending &= ~4u; }
+        if (pending && spin > 32) __builtin_amdgcn_s_sleep(1);
+    }
+    if (pend) *pend = pending;
+    return pending == 0;
+}
+
 // Waits until one granule pair carries generation `gen` (same address in every lane: one request per wave).
 __device__ __forceinline__ bool rs_wait(const u64* g, unsigned gen)
 {

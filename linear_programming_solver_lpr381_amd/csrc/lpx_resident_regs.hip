@@ -13,18 +13,22 @@
 //   NT = 768, two columns per lane, 3 waves per SIMD (168 VGPRs): 22 rows of a 1282-column node per workgroup -> 35 workgroups per
 //     node -> SEVEN config-4 nodes in flight instead of the LDS form's four (845-880 nodes/s; 26 rows / 8 nodes 802, 28 rows / 9 nodes
 //     729: beyond 22 rows that tile spills into scratch on the critical path);
-//   NT = 512, THREE columns per lane, 2 waves per SIMD (256 VGPRs, 2 spilled): 28 rows -> 28 workgroups per node -> NINE nodes in
-//     flight: 964 nodes/s on the box where the first form gives 845 (31 rows / ten nodes spill 40 registers: 805).
+//   NT = 512, THREE columns per lane, 2 waves per SIMD (256 VGPRs): 28 rows -> 28 workgroups per node -> NINE nodes in flight: 964
+//     nodes/s on the box where the first form gives 845 (31 rows / ten nodes spill 40 registers: 805);
+//   the same with the 120 KB of LDS the row buffers leave free holding 11-12 MORE rows of the node (swept K0b-style after the register
+//     rows: +1.5 us per step): 26 + 11 rows -> 21 workgroups per node -> TWELVE nodes in flight: 1170-1180 nodes/s (24-26 register rows
+//     alike; 27: 1046, 28: 1024 -- the loop's own registers spill).
 // Everything else -- the tagged-granule
 // exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
 // lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
 // the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB.
 #include "lpx_resident.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace lpx {
 
-struct ResGroupParamsR { const ResNode* nodes; int chunk; int mute; };
+struct ResGroupParamsR { const ResNode* nodes; int chunk; int mute; int rt; };   // rt = rows a workgroup may hold (registers + LDS): sizes the per-row LDS arrays
 
 #ifdef LPX_STAMPS
 #define RR_T0 unsigned long long rg_prev_ = __builtin_amdgcn_s_memtime();
@@ -82,6 +86,15 @@ __device__ __forceinline__ int rr_first_min_below(const double* v, int L, double
 // width of the register tile and of the LDS rows: the first multiple of 2 and of kc at or above C
 __host__ __device__ __forceinline__ int rr_tile_width(int C, int kc) { const int u = (kc & 1) ? 2 * kc : kc; return (C + u - 1) / u * u; }
 
+// KG granule pairs per lane and round (i, i + NT, [i + 2 NT]): two for the two-column form, three for the three-column form, so that
+// a workgroup covers the pivot row (as wide as its tile) in ONE round trip
+template <int KG, int NT>
+__device__ __forceinline__ bool rr_gather(const u64* g, int base, int cnt, unsigned gen, double* val, unsigned max_spin = RS_SPIN_MAX, unsigned* pend = nullptr)
+{
+    if (KG == 3) return rs_gather3(g, base, base + NT, base + 2 * NT, cnt, gen, val, max_spin, pend);
+    return rs_gather2(g, base, base + NT, cnt, gen, val, max_spin, pend);
+}
+
 // WPE = waves per SIMD the kernel is compiled for (NT / 256): sets the register budget.  KC = columns per lane: 2 for tableaux up to
 // 2 NT columns; 3 lets 512 lanes (two waves per SIMD, 256 VGPRs each) carry a 1536-column node -- fewer lanes pay the loop's own ~80
 // registers, so a CU holds 28 rows of a config-4 node instead of 22 and the chip NINE nodes instead of seven.
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     if (GP.mute == 3 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0) rs_wait_for_abort(st);
     const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x;
     const int C = P.C, m = P.R - 1, rhsc = C - 1;
-    const int rpw = (m + G - 1) / G;            // <= RPW (host)
+    const int rpw = (m + G - 1) / G;            // <= GP.rt (host): the first RPW of them live in registers, the rest in LDS
     const int row0 = w * rpw;
     const int nloc = max(0, min(rpw, m - row0));
     const int mp = (m + 1) & ~1;
@@ -114,10 +127,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     double* prow = obj + ld;                    // [ld]
     double* rowbuf = prow + ld;                 // [ld]   the owner's pivot row as it stands (before the division)
     double* col = rowbuf + ld;                  // [mp]   gathered per-row values
-    double* fac = col + mp;                     // [RPW+1]
-    double* ca = fac + RPW + 1;                 // [RPW]  column qc of the local rows
-    double* cr = ca + RPW;                      // [RPW]  RHS column of the local rows, kept current from round to round (as the tile's own)
-    double* fn = cr + RPW;                      // [RPW]  column qc as the lookahead left it = the next pivot's factors when it enters
+    const int rt = GP.rt;                       // >= RPW
+    double* fac = col + mp;                     // [rt+1]
+    double* ca = fac + rt + 1;                  // [rt]   column qc of the local rows
+    double* cr = ca + rt;                       // [rt]   RHS column of the local rows, kept current from round to round (as the tile's own)
+    double* fn = cr + rt;                       // [rt]   column qc as the lookahead left it = the next pivot's factors when it enters
+    // Local rows RPW .. nloc-1 live in LDS (the 120 KB the arrays above leave free: ~11 more rows of a config-4 node, so a node
+    // takes 20 workgroups instead of 28 and TWELVE are in flight).  They are swept K0b-style, lane j mod NT on column j.
+    double* lrows = fn + rt + 1;                // [nl][ld], 16-byte aligned like the arrays in front (ld, mp even; 4 rt + 2 doubles of per-row arrays)
+    const int nl = max(0, nloc - RPW);
 
     const int jt = KC * t;                      // this lane's columns: jt .. jt + KC - 1
     const bool mine = jt < ld;
@@ -134,6 +152,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 for (int c = 0; c < KC; ++c) reg[i][c] = src[c];
             }
         }
+    }
+    for (int i = 0; i < nl; ++i) {
+        const double* src = P.T + (size_t)(row0 + RPW + i) * gld;
+        for (int j = 2 * t; j < ld; j += 2 * NT) *reinterpret_cast<double2*>(lrows + (size_t)i * ld + j) = *reinterpret_cast<const double2*>(src + j);
     }
     {
         const double* src = P.T + (size_t)m * gld;
@@ -161,6 +183,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 dst[i] = __longlong_as_double(b);
             }
         }
+        if (t < nl) dst[RPW + t] = lrows[(size_t)t * ld + c];
     };
 
     int phase = P.dual ? st->phase : 2;
@@ -238,7 +261,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         u64* xp = P.xp + 2 * (size_t)par * (gld + 8);
         if (w == owner) {
             // the pivot row out of the registers: register `rl` of every lane (rl is uniform, the chain is unrolled)
-            if (mine) {
+            if (rl >= RPW) {                   // an LDS row
+                const double* src = lrows + (size_t)(rl - RPW) * ld;
+                for (int j = 2 * t; j < ld; j += 2 * NT) *reinterpret_cast<double2*>(rowbuf + j) = *reinterpret_cast<const double2*>(src + j);
+            } else if (mine) {
                 double v[KC];
 #pragma unroll
                 for (int c = 0; c < KC; ++c) v[c] = reg[0][c];
@@ -276,16 +302,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             __builtin_amdgcn_s_sleep(15);
             for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
             bool first = true;
-            for (int base = t; base < C; base += NT * 2) {
-                double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < C ? 2 : 1;
+            for (int base = t; base < C; base += NT * KC) {
+                double val[KC]; const int cnt = min(KC, (C - base + NT - 1) / NT);
                 unsigned pend = (1u << cnt) - 1u;
-                if (first && !rs_gather2(xp, i0, i1, cnt, gen, val, 1u, &pend)) {
+                if (first && !rr_gather<KC, NT>(xp, base, cnt, gen, val, 1u, &pend)) {
                     if (!rs_wait(xp + 2 * (size_t)(C - 1), gen)) fail = 1;
                 }
                 first = false;
-                if (pend && !rs_gather2(xp, i0, i1, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
-                prow[i0] = val[0];
-                if (cnt > 1) prow[i1] = val[1];
+                if (pend && !rr_gather<KC, NT>(xp, base, cnt, gen, val, RS_SPIN_MAX, &pend)) fail = 1;
+#pragma unroll
+                for (int u = 0; u < KC; ++u) if (u < cnt) prow[base + u * NT] = val[u];
             }
         } else {
             __builtin_amdgcn_s_sleep(15);
@@ -298,11 +324,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 q = fail ? -1 : (int)hval[0];
             }
             if (q >= 0)
-                for (int base = t; base < C; base += NT * 2) {
-                    double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < C ? 2 : 1;
-                    if (!rs_gather2(xp, i0, i1, cnt, gen, val)) fail = 1;
-                    prow[i0] = val[0];
-                    if (cnt > 1) prow[i1] = val[1];
+                for (int base = t; base < C; base += NT * KC) {
+                    double val[KC]; const int cnt = min(KC, (C - base + NT - 1) / NT);
+                    if (!rr_gather<KC, NT>(xp, base, cnt, gen, val)) fail = 1;
+#pragma unroll
+                    for (int u = 0; u < KC; ++u) if (u < cnt) prow[base + u * NT] = val[u];
                 }
         }
         if (__syncthreads_or(fail)) { hung = true; break; }
@@ -310,11 +336,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         RR_T(3);
 
         // ---- column factors of this pivot, objective replica, next entering column ------------------------------------------
-        if (fn_col == q) { if (t < RPW) fac[t] = fn[t]; }                       // the lookahead of the last round already formed this column
+        if (fn_col == q) { if (t < rt) fac[t] = fn[t]; }                        // the lookahead of the last round already formed this column
         else column_out(q, fac);
-        if (t == NT - 1) fac[RPW] = obj[q];
+        if (t == NT - 1) fac[rt] = obj[q];
         rs_barrier_lds();
-        const double fobj = fac[RPW];
+        const double fobj = fac[rt];
         const int skip = (w == owner) ? rl : -1;
         MinIdx best; best.v = -eps; best.i = INT_MAX;
         if (t < RS_RT) {
@@ -387,6 +413,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     }
             }
         }
+        if (nl > 0) {                           // the rows in LDS: column pair outermost (the pivot-row pair stays in registers), two rows in flight
+            for (int j = 2 * t; j < ld; j += 2 * NT) {
+                const double2 p2 = *reinterpret_cast<const double2*>(prow + j);
+                double* lr = lrows + j;
+                int i = 0;
+                for (; i + 2 <= nl; i += 2) {
+                    double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld), x1 = *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld);
+                    const double f0 = fac[RPW + i], f1 = fac[RPW + i + 1];
+                    double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod;
+                    prod = f1 * p2.x; x1.x = x1.x - prod; prod = f1 * p2.y; x1.y = x1.y - prod;
+                    *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0; *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld) = x1;
+                }
+                if (i < nl) {
+                    double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld);
+                    const double f0 = fac[RPW + i];
+                    double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod;
+                    *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0;
+                }
+                if (skip >= RPW) {              // row r of the owner = the normalised pivot row; the padding columns keep what they held
+                    double2 v = p2;
+                    if (j >= C) v.x = rowbuf[j];
+                    if (j + 1 >= C) v.y = rowbuf[j + 1];
+                    *reinterpret_cast<double2*>(lr + (size_t)(skip - RPW) * ld) = v;
+                }
+            }
+        }
         rs_barrier_lds();                       // fac / ca / cr / prow / rowbuf are rewritten by the next round
         RR_T(5);
     }
@@ -406,6 +458,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     for (int c = 0; c < KC; ++c) dst[c] = reg[i][c];
                 }
             }
+    }
+    for (int i = 0; i < nl; ++i) {
+        double* dst = P.T + (size_t)(row0 + RPW + i) * gld;
+        for (int j = 2 * t; j < ld; j += 2 * NT) *reinterpret_cast<double2*>(dst + j) = *reinterpret_cast<const double2*>(lrows + (size_t)i * ld + j);
     }
     if (w == 0) {
         double* dst = P.T + (size_t)m * gld;
@@ -427,43 +483,56 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 // shapes the register kernel is instantiated for: (lanes, rows per workgroup, columns per lane)
-static constexpr int RR_NT_A = 768, RR_RPW_A = 22;     // tableaux up to 1536 columns, two columns per lane (r03's first form: seven config-4 nodes)
-static constexpr int RR_NT_B = 512, RR_RPW_B = 48;     // up to 1024 columns
-static constexpr int RR_NT_C = 512, RR_RPW_C = 28;     // up to 1536 columns, THREE columns per lane: nine config-4 nodes
+// (register rows; the LDS takes ~12 more rows of a 1284-wide node, ~15 of a 1024-wide one: resident_regs_shape)
+static constexpr int RR_NT_A = 768, RR_RPW_A = 22;     // tableaux up to 1536 columns, two columns per lane (r03's first form)
+static constexpr int RR_NT_B = 512, RR_RPW_B = 40;     // up to 1024 columns (48 rows spilled 74 registers once the LDS rows were there; 40: 3)
+static constexpr int RR_NT_C = 512, RR_RPW_C = 26;     // up to 1536 columns, THREE columns per lane: 26 + 11 rows -> 21 workgroups per config-4 node -> twelve nodes
 
 static int rr_kc(int cfg) { return cfg == 3 ? 3 : 2; }
+static int rr_reg_rows(int cfg) { return cfg == 1 ? RR_RPW_B : (cfg == 2 ? RR_RPW_A : RR_RPW_C); }
+static constexpr size_t RR_LDS_BUDGET = (size_t)158 * 1024;   // dynamic LDS of a workgroup (160 KB per CU, the static scan records beside it)
 
-size_t resident_regs_lds(int R, int C, int rpw_max, int cfg)
+// rt = rows a workgroup may hold (the per-row arrays are sized for it); the rows beyond the configuration's register rows live in LDS
+size_t resident_regs_lds(int R, int C, int rt, int cfg)
 {
     const int m = R - 1, ld = rr_tile_width(C, rr_kc(cfg));
-    return sizeof(double) * ((size_t)3 * ld + (size_t)((m + 1) & ~1) + (size_t)4 * rpw_max + 2);
+    const int lrows = std::max(0, rt - rr_reg_rows(cfg));
+    return sizeof(double) * ((size_t)3 * ld + (size_t)((m + 1) & ~1) + (size_t)4 * rt + 2 + (size_t)lrows * ld);
 }
 
 // 0 = this group does not fit the register kernel; else the configuration (1 = B, 2 = A, 3 = C), with *rpw_max the rows a
-// workgroup can hold.  min_ld = the smallest row pitch of the group: the tile must not be wider than a row in memory.
-int resident_regs_shape(int maxC, int min_ld, int* rpw_max)
+// workgroup can hold: the configuration's register rows plus what the LDS takes beside the row buffers (a node of mmax + 1 rows).
+// min_ld = the smallest row pitch of the group: the tile must not be wider than a row in memory.
+int resident_regs_shape(int maxC, int min_ld, int mmax, int* rpw_max)
 {
     static const int wide = [] { const char* e = std::getenv("LPX_RESIDENT_REGS_KC"); return e ? std::atoi(e) : 3; }();   // diagnostic: 2 = the two-column form for wide nodes
-    if (rr_tile_width(maxC, 2) <= 2 * RR_NT_B && rr_tile_width(maxC, 2) <= min_ld) { *rpw_max = RR_RPW_B; return 1; }
-    if (wide == 3 && rr_tile_width(maxC, 3) <= 3 * RR_NT_C && rr_tile_width(maxC, 3) <= min_ld) { *rpw_max = RR_RPW_C; return 3; }
-    if (rr_tile_width(maxC, 2) <= 2 * RR_NT_A && rr_tile_width(maxC, 2) <= min_ld) { *rpw_max = RR_RPW_A; return 2; }
-    return 0;
+    static const bool lds_rows = [] { const char* e = std::getenv("LPX_RESIDENT_REGS_LDS"); return !(e && e[0] == '0'); }();   // diagnostic: 0 = register rows only
+    int cfg = 0;
+    if (rr_tile_width(maxC, 2) <= 2 * RR_NT_B && rr_tile_width(maxC, 2) <= min_ld) cfg = 1;
+    else if (wide == 3 && rr_tile_width(maxC, 3) <= 3 * RR_NT_C && rr_tile_width(maxC, 3) <= min_ld) cfg = 3;
+    else if (rr_tile_width(maxC, 2) <= 2 * RR_NT_A && rr_tile_width(maxC, 2) <= min_ld) cfg = 2;
+    if (!cfg) return 0;
+    const int regs = rr_reg_rows(cfg), ld = rr_tile_width(maxC, rr_kc(cfg));
+    const long long fixed = 3LL * ld + ((mmax + 1) & ~1) + 4LL * regs + 2;
+    const long long left = (long long)(RR_LDS_BUDGET / sizeof(double)) - fixed;
+    *rpw_max = regs + (lds_rows && left > 0 ? (int)(left / (ld + 4)) : 0);
+    return cfg;
 }
 
 hipError_t resident_regs_init()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
     return e;
 }
 
-hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, size_t lds, int chunk, hipStream_t s)
+hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, int rt, size_t lds, int chunk, hipStream_t s)
 {
-    ResGroupParamsR p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
+    ResGroupParamsR p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk; p.rt = std::max(rt, rr_reg_rows(cfg));
     static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
     p.mute = mute;
     if (cfg == 2) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);

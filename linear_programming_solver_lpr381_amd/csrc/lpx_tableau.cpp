@@ -565,26 +565,26 @@ ResGroupBuf g_resgroup;
 
 // which kernel the last resident_group_plan chose: 0 = rows in LDS (lpx_resident_group), else the workgroup size of the
 // register-resident variant (lpx_resident_group_r); read by run_resident_group right after (handles are used from one thread)
-static thread_local int tl_plan_nt = 0;
+static thread_local int tl_plan_nt = 0, tl_plan_rt = 0;     // register-resident kernel: configuration, rows a workgroup may hold
 
 // The register-resident variant (node rows in VGPRs): more nodes per launch when a node is wide enough to need many CUs' LDS.
 // Returns the nodes per launch it would give (0 = not applicable) and fills grid / lds / nt.
-static int resident_regs_plan(lpx_tableau** ts, int count, int cus, int* grid, size_t* lds, int* nt)
+static int resident_regs_plan(lpx_tableau** ts, int count, int cus, int* grid, size_t* lds, int* nt, int* rt)
 {
     static const bool enabled = [] { const char* e = std::getenv("LPX_RESIDENT_REGS"); return !(e && e[0] == '0'); }();
     if (!enabled) return 0;
     int maxC = 2, mmax = 1, mmin = 1 << 30, min_ld = 1 << 30;
     for (int i = 0; i < count; ++i) { maxC = std::max(maxC, ts[i]->C); mmax = std::max(mmax, ts[i]->R - 1); mmin = std::min(mmin, ts[i]->R - 1); min_ld = std::min(min_ld, ts[i]->ld); }
     int rpw_max = 0;
-    const int n = resident_regs_shape(maxC, min_ld, &rpw_max);       // the kernel configuration
+    const int n = resident_regs_shape(maxC, min_ld, mmax, &rpw_max); // the kernel configuration
     if (!n) return 0;
     int g = (mmax + rpw_max - 1) / rpw_max;                 // workgroups per node: every node's rows per workgroup <= rpw_max
     if (g > mmin || g > cus) return 0;
     { const int rpw = (mmax + g - 1) / g; g = (mmax + rpw - 1) / rpw; }          // no idle workgroups for the tallest node
     size_t need = 0;
     for (int i = 0; i < count; ++i) need = std::max(need, resident_regs_lds(ts[i]->R, ts[i]->C, rpw_max, n));
-    if (need > (size_t)96 * 1024) return 0;
-    *grid = g; *lds = need; *nt = n;
+    if (need > (size_t)158 * 1024) return 0;
+    *grid = g; *lds = need; *nt = n; *rt = rpw_max;
     return cus / g;
 }
 
@@ -623,17 +623,17 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
         if (need <= lds_max) {
             *grid = g; *slots = n; *lds = need;
             // rows in registers instead, when that puts more nodes on the chip at once (and there are enough nodes to use them)
-            int rg = 0, rnt = 0; size_t rlds = 0;
-            const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt);
+            int rg = 0, rnt = 0, rrt = 0; size_t rlds = 0;
+            const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt, &rrt);
             static const bool force_regs = [] { const char* e = std::getenv("LPX_RESIDENT_REGS"); return e && e[0] == '2'; }();   // diagnostic: whenever it applies
-            if (rslots >= 1 && (force_regs || (rslots > n && count > n))) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; }
+            if (rslots >= 1 && (force_regs || (rslots > n && count > n))) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; tl_plan_rt = rrt; }
             return 1;
         }
     }
     {   // nothing fits the LDS form: the register form alone
-        int rg = 0, rnt = 0; size_t rlds = 0;
-        const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt);
-        if (rslots >= 1) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; return 1; }
+        int rg = 0, rnt = 0, rrt = 0; size_t rlds = 0;
+        const int rslots = resident_regs_plan(ts, count, cus, &rg, &rlds, &rnt, &rrt);
+        if (rslots >= 1) { *grid = rg; *slots = std::min(rslots, std::min(count, max_slots)); *lds = rlds; tl_plan_nt = rnt; tl_plan_rt = rrt; return 1; }
     }
     return 0;
 }
@@ -643,7 +643,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
                        DevState* resume = nullptr)
 {
     ResGroupBuf& g = g_resgroup;
-    const int plan_nt = tl_plan_nt;             // 0: rows in LDS; else the configuration of the register-resident kernel
+    const int plan_nt = tl_plan_nt, plan_rt = tl_plan_rt;   // 0: rows in LDS; else the configuration of the register-resident kernel
     if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (g.cap < count) {
         hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
@@ -703,7 +703,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         }
         // the kernel writes each node's new state into the pinned mirror (ResNode::st_host): nothing is copied back
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));
-        if (plan_nt) LPX_HIP_TRY(launch_resident_regs(g.d, n, grid, plan_nt, lds, chunk, g.stream));
+        if (plan_nt) LPX_HIP_TRY(launch_resident_regs(g.d, n, grid, plan_nt, plan_rt, lds, chunk, g.stream));
         else LPX_HIP_TRY(launch_resident_group(g.d, n, grid, lds, chunk, g.stream));
         LPX_HIP_TRY(hipStreamSynchronize(g.stream));
         bool aborted = false;
