@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--bnb-mid-n", type=int, default=128)
     ap.add_argument("--bnb-mid-m", type=int, default=32)
     ap.add_argument("--bnb-mid-seed", type=int, default=20251003)
-    ap.add_argument("--bnb-mid-concurrent", type=int, default=64)
+    ap.add_argument("--bnb-mid-concurrent", type=int, default=256)
     ap.add_argument("--bnb-mid-nodes", type=int, default=0, help="GLOBAL node budget of the mid-size leg (0 = to optimality)")
     ap.add_argument("--bnb-warm-nodes", type=int, default=8000, help="GLOBAL node budget of the warm-start leg")
     ap.add_argument("--bnb-warm-concurrent", type=int, default=64)
