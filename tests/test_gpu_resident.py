@@ -389,3 +389,44 @@ def test_column_owning_resident_kernel_is_bit_identical(oracle):
     env = dict(os.environ, LPX_RESIDENT_COL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_register_group_forms_agree_bit_for_bit(oracle):
+    """lpx_resident_group_r in its forms -- three columns per lane with rows in the LDS beside the registers (default), without the LDS
+    rows, two columns per lane -- against the LDS-resident group kernel and the streaming kernels: the same config-4 node LPs (root
+    shape 770x1282 and deeper levels: the tile's padding columns differ), final tableaux, bases, pivot counts and statuses bitwise.
+    The environment switches are read once per process, hence one child process per form."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent('''
+        import hashlib, numpy as np
+        import linear_programming_solver_lpr381_amd as L
+        from linear_programming_solver_lpr381_amd import synth
+        c, A, rel, b = synth.binary_ip(512, 256)
+        n = len(c)
+        h = hashlib.sha256()
+        hs = []
+        for depth in (1, 2, 3, 5):
+            rows = [-np.eye(n)[k] if k % 2 == 0 else np.eye(n)[k] for k in range(depth)]      # x_k >= 1 as -x_k <= -1, x_k <= 0
+            rhs = [-1.0 if k % 2 == 0 else 0.0 for k in range(depth)]
+            T, basis = synth.primal_tableau_from(c, np.vstack([A] + rows), np.concatenate([b, rhs]))
+            for copy in range(4):                                      # 16 nodes: more than the LDS form holds at a time
+                hs.append(L.DeviceTableau.from_host(T, basis))
+        o = L.default_opts(True, fdf_guard=10000, cleanup=1)
+        po = L.default_opts(False)
+        st, stats = L.multi_run(hs, [1] * len(hs), po, o)
+        for dt, s, k in zip(hs, st, stats):
+            Tg, bg = dt.download()
+            h.update(np.ascontiguousarray(Tg).view(np.uint8)); h.update(np.ascontiguousarray(bg).view(np.uint8))
+            h.update(np.array([s, k["pivots"]], dtype=np.int64).view(np.uint8))
+        print("DIGEST", h.hexdigest(), sum(k["pivots"] for k in stats))
+    ''')
+    base = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    forms = {"default": {}, "no LDS rows": {"LPX_RESIDENT_REGS_LDS": "0"}, "two columns": {"LPX_RESIDENT_REGS_KC": "2"},
+             "LDS form": {"LPX_RESIDENT_REGS": "0"}, "streaming": {"LPX_RESIDENT_GROUP": "0"}}
+    seen = {}
+    for name, extra in forms.items():
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, name + ": " + r.stdout + r.stderr
+        seen[name] = r.stdout.split("DIGEST", 1)[1].split()
+    assert len({tuple(v) for v in seen.values()}) == 1, seen
+    assert int(seen["default"][1]) > 1000, seen
