@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--roofline-pivots", type=int, default=400)
     ap.add_argument("--headline-pivots", type=int, default=200)
     ap.add_argument("--cpu-sample-pivots", type=int, default=240)
-    ap.add_argument("--bnb-nodes", type=int, default=1600, help="GLOBAL node budget of the config 4 leg (strong scaling)")
+    ap.add_argument("--bnb-nodes", type=int, default=3200, help="GLOBAL node budget of the config 4 leg (strong scaling)")
     ap.add_argument("--bnb-prune-n", type=int, default=60)
     ap.add_argument("--bnb-prune-m", type=int, default=12)
     ap.add_argument("--bnb-concurrent", type=int, default=64)
