@@ -98,7 +98,62 @@ __device__ __forceinline__ bool rr_gather(const u64* g, int base, int cnt, unsig
 // WPE = waves per SIMD the kernel is compiled for (NT / 256): sets the register budget.  KC = columns per lane: 2 for tableaux up to
 // 2 NT columns; 3 lets 512 lanes (two waves per SIMD, 256 VGPRs each) carry a 1536-column node -- fewer lanes pay the loop's own ~80
 // registers, so a CU holds 28 rows of a config-4 node instead of 22 and the chip NINE nodes instead of seven.
-template <int NT, int RPW, int WPE, int KC>
+// ---- rank-1 update of the local rows (registers, then the rows in LDS) with the factors in `fac` and the normalised row in `prow`, :250-256;
+//      `skip_` = the local row that IS the pivot row (owner only, else -1): it is put back afterwards from the normalised row (a predicate per
+//      row would cost two scalar mask registers each); rows beyond nloc hold dummies nobody reads.  A macro, not a lambda: a lambda that
+//      WRITES the register tile through its capture moved the whole tile into scratch memory.
+#define RR_UPDATE(skip_) do { const int rr_sk = (skip_); \
+    if (mine) { \
+        double p[KC]; \
+_Pragma("unroll") \
+        for (int c = 0; c < KC; ++c) p[c] = prow[jt + c]; \
+_Pragma("unroll") \
+        for (int i = 0; i < RPW; ++i) { \
+            const double f = fac[i]; \
+_Pragma("unroll") \
+            for (int c = 0; c < KC; ++c) { const double prod = f * p[c]; reg[i][c] = reg[i][c] - prod; } \
+        } \
+        if (rr_sk >= 0) { \
+_Pragma("unroll") \
+            for (int c = 0; c < KC; ++c) if (jt + c >= C) p[c] = rowbuf[jt + c]; \
+_Pragma("unroll") \
+            for (int i = 0; i < RPW; ++i) \
+                if (i == rr_sk) { \
+_Pragma("unroll") \
+                    for (int c = 0; c < KC; ++c) reg[i][c] = p[c]; \
+                } \
+        } \
+    } \
+    if (nl > 0) { \
+        for (int j = 2 * t; j < ld; j += 2 * NT) { \
+            const double2 p2 = *reinterpret_cast<const double2*>(prow + j); \
+            double* lr = lrows + j; \
+            int i = 0; \
+            for (; i + 2 <= nl; i += 2) { \
+                double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld), x1 = *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld); \
+                const double f0 = fac[RPW + i], f1 = fac[RPW + i + 1]; \
+                double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod; \
+                prod = f1 * p2.x; x1.x = x1.x - prod; prod = f1 * p2.y; x1.y = x1.y - prod; \
+                *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0; *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld) = x1; \
+            } \
+            if (i < nl) { \
+                double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld); \
+                const double f0 = fac[RPW + i]; \
+                double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod; \
+                *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0; \
+            } \
+            if (rr_sk >= RPW) { \
+                double2 v = p2; \
+                if (j >= C) v.x = rowbuf[j]; \
+                if (j + 1 >= C) v.y = rowbuf[j + 1]; \
+                *reinterpret_cast<double2*>(lr + (size_t)(rr_sk - RPW) * ld) = v; \
+            } \
+        } \
+    } \
+} while (0)
+
+// DEFER: the rank-1 update of pivot k is applied while the workgroup would otherwise wait for pivot k+1's row (see the round loop).
+template <int NT, int RPW, int WPE, int KC, bool DEFER>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void lpx_resident_group_r(ResGroupParamsR GP)
 {
     extern __shared__ __align__(16) double rr_lds[];
@@ -200,8 +255,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     column_out(rhsc, cr);
     int fn_col = -1;
 
+    // DEFER: the update of pivot k (factors `fac`, normalised row `prow`, the owner's row `pend_skip`) stays PENDING through the end of
+    // round k and the decision of round k+1, and is applied where a workgroup used to sleep and poll: between the decision and the
+    // arrival of pivot k+1's row (the owner of that row publishes first and updates then).  Whoever needs a value of the tile before
+    // that forms it as the update would (mul, then sub): the owner the pivot row it extracts, the republish path its column -- the
+    // lookahead has always worked that way.  On the way out (final status, end of the launch) the pending update is applied behind the loop.
+    bool pend_upd = false; int pend_skip = -1;
+    if (DEFER) { for (int i = t; i <= rt; i += NT) fac[i] = 0.0; __syncthreads(); }
     RR_T0
     for (int k = 0; k < GP.chunk; ++k) {
+        int fail = 0, q = -1;
         if (publish_now) {
             if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
             if (phase != 1 && qc >= 0) column_out(qc, ca);
@@ -209,7 +272,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (t < nloc) {
                 const double rhs0 = cr[t];
                 double v = rhs0;
-                if (phase != 1) { const double a0 = qc >= 0 ? ca[t] : 0.0; v = a0 > eps ? rhs0 / a0 : __builtin_inf(); }   // :229-233
+                if (phase != 1) {
+                    double a0 = qc >= 0 ? ca[t] : 0.0;
+                    if (DEFER && pend_upd && qc >= 0) {                         // column qc as the pending update will leave it
+                        if (t == pend_skip) a0 = prow[qc];
+                        else { const double prod = fac[t] * prow[qc]; a0 = a0 - prod; }
+                    }
+                    v = a0 > eps ? rhs0 / a0 : __builtin_inf();                 // :229-233
+                }
                 rs_publish(P.xr + 2 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t), v, gen + 1u);
             }
             publish_now = false;
@@ -217,7 +287,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         ++gen;
         const int par = (int)(gen & 1u);
         // ---- exchange 1: one value per row ----------------------------------------------------------------------------
-        int fail = 0;
         for (int base = t; base < m; base += NT * 2) {
             double val[2]; const int i0 = base, i1 = base + NT; const int cnt = i1 < m ? 2 : 1;
             if (!rs_gather2(P.xr + 2 * (size_t)par * P.mcap, i0, i1, cnt, gen, val)) fail = 1;
@@ -228,7 +297,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         RR_T(1);
 
         // ---- the decision of lpx_select_body, replicated (as lpx_resident_group) ------------------------------------------
-        int q = -1, final_status = LPX_RUNNING;
+        int final_status = LPX_RUNNING;
         bool republish = false;
         r = -1;
         for (int hop = 0; hop < 3 && final_status == LPX_RUNNING && r < 0 && !republish; ++hop) {
@@ -261,9 +330,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         u64* xp = P.xp + 2 * (size_t)par * (gld + 8);
         if (w == owner) {
             // the pivot row out of the registers: register `rl` of every lane (rl is uniform, the chain is unrolled)
+            const bool fix = DEFER && pend_upd;                                 // the row as the pending update will leave it
+            const bool was = fix && rl == pend_skip;                            // ... which made it the normalised row of the last pivot
+            const double fp = fix ? fac[rl] : 0.0;
             if (rl >= RPW) {                   // an LDS row
                 const double* src = lrows + (size_t)(rl - RPW) * ld;
-                for (int j = 2 * t; j < ld; j += 2 * NT) *reinterpret_cast<double2*>(rowbuf + j) = *reinterpret_cast<const double2*>(src + j);
+                for (int j = 2 * t; j < ld; j += 2 * NT) {
+                    double2 x = *reinterpret_cast<const double2*>(src + j);
+                    if (fix) {
+                        const double2 p2 = *reinterpret_cast<const double2*>(prow + j);
+                        if (was) x = p2;
+                        else { double prod = fp * p2.x; x.x = x.x - prod; prod = fp * p2.y; x.y = x.y - prod; }
+                    }
+                    *reinterpret_cast<double2*>(rowbuf + j) = x;
+                }
             } else if (mine) {
                 double v[KC];
 #pragma unroll
@@ -274,6 +354,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
                         for (int c = 0; c < KC; ++c) v[c] = reg[i][c];
                     }
+                if (fix) {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        const double pc = prow[jt + c];
+                        if (was) v[c] = pc; else { const double prod = fp * pc; v[c] = v[c] - prod; }
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < KC; ++c) rowbuf[jt + c] = v[c];
             }
@@ -288,19 +375,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             }
             if (q >= 0) {
                 const double piv = rowbuf[q];
+                if (DEFER) rs_barrier_lds();                                    // rowbuf[q] is overwritten below: every lane has its copy first
                 for (int j = t; j < C; j += NT) {
                     const double p = rowbuf[j] / piv;                           // true division, :250
                     rs_publish(xp + 2 * (size_t)j, p, gen);
-                    prow[j] = p;
+                    if (DEFER) rowbuf[j] = p; else prow[j] = p;                 // DEFER: prow still holds the pending update's row
                 }
             }
             if (phase == 1) {
                 __syncthreads();
                 if (t == 0) rs_publish(xp + 2 * (size_t)gld, (double)q, gen);   // header {q} behind the row
             }
+        }
+        if (DEFER) {
+            const bool had = pend_upd;
+            RR_UPDATE(pend_skip); pend_upd = false; pend_skip = -1;    // unconditional: before the first pivot fac is zero (x - 0 * p = x)
+            rs_barrier_lds();                   // prow may be rewritten now
+            if (w == owner) { if (q >= 0) for (int j = t; j < C; j += NT) prow[j] = rowbuf[j]; }
+            else if (!had) { __builtin_amdgcn_s_sleep(15); for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5); if (phase == 1) __builtin_amdgcn_s_sleep(25); }
+        }
+        if (w == owner) {
         } else if (phase != 1) {
-            __builtin_amdgcn_s_sleep(15);
-            for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
+            if (!DEFER) { __builtin_amdgcn_s_sleep(15); for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5); }
             bool first = true;
             for (int base = t; base < C; base += NT * KC) {
                 double val[KC]; const int cnt = min(KC, (C - base + NT - 1) / NT);
@@ -314,9 +410,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 for (int u = 0; u < KC; ++u) if (u < cnt) prow[base + u * NT] = val[u];
             }
         } else {
-            __builtin_amdgcn_s_sleep(15);
-            for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
-            __builtin_amdgcn_s_sleep(25);                                       // the owner scans its row first
+            if (!DEFER) {
+                __builtin_amdgcn_s_sleep(15);
+                for (int z = 0; z < C; z += 1024) __builtin_amdgcn_s_sleep(5);
+                __builtin_amdgcn_s_sleep(25);                                   // the owner scans its row first
+            }
             // the header first (one granule, the same address in every lane), then the row
             {
                 double hval[2];
@@ -389,56 +487,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (qc >= 0) fn_col = qc;
         }
         RR_T(0);
-        // ---- rank-1 update of the local rows in registers, :250-256.  Straight-line over all RPW registers: rows beyond nloc hold
-        //      dummies nobody reads, and the owner's pivot row -- which the update must leave alone (:252) -- is put back afterwards
-        //      from the normalised row (a predicate per row would cost two scalar mask registers each, hoisted out of the round loop)
-        if (mine) {
-            double p[KC];
-#pragma unroll
-            for (int c = 0; c < KC; ++c) p[c] = prow[jt + c];
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const double f = fac[i];
-#pragma unroll
-                for (int c = 0; c < KC; ++c) { const double prod = f * p[c]; reg[i][c] = reg[i][c] - prod; }
-            }
-            if (skip >= 0) {                                                    // row r of the owner = the normalised pivot row, :249-250
-#pragma unroll
-                for (int c = 0; c < KC; ++c) if (jt + c >= C) p[c] = rowbuf[jt + c];   // the padding columns keep what they held
-#pragma unroll
-                for (int i = 0; i < RPW; ++i)
-                    if (i == skip) {
-#pragma unroll
-                        for (int c = 0; c < KC; ++c) reg[i][c] = p[c];
-                    }
-            }
-        }
-        if (nl > 0) {                           // the rows in LDS: column pair outermost (the pivot-row pair stays in registers), two rows in flight
-            for (int j = 2 * t; j < ld; j += 2 * NT) {
-                const double2 p2 = *reinterpret_cast<const double2*>(prow + j);
-                double* lr = lrows + j;
-                int i = 0;
-                for (; i + 2 <= nl; i += 2) {
-                    double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld), x1 = *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld);
-                    const double f0 = fac[RPW + i], f1 = fac[RPW + i + 1];
-                    double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod;
-                    prod = f1 * p2.x; x1.x = x1.x - prod; prod = f1 * p2.y; x1.y = x1.y - prod;
-                    *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0; *reinterpret_cast<double2*>(lr + (size_t)(i + 1) * ld) = x1;
-                }
-                if (i < nl) {
-                    double2 x0 = *reinterpret_cast<double2*>(lr + (size_t)i * ld);
-                    const double f0 = fac[RPW + i];
-                    double prod = f0 * p2.x; x0.x = x0.x - prod; prod = f0 * p2.y; x0.y = x0.y - prod;
-                    *reinterpret_cast<double2*>(lr + (size_t)i * ld) = x0;
-                }
-                if (skip >= RPW) {              // row r of the owner = the normalised pivot row; the padding columns keep what they held
-                    double2 v = p2;
-                    if (j >= C) v.x = rowbuf[j];
-                    if (j + 1 >= C) v.y = rowbuf[j + 1];
-                    *reinterpret_cast<double2*>(lr + (size_t)(skip - RPW) * ld) = v;
-                }
-            }
-        }
+        if (DEFER) { pend_upd = true; pend_skip = skip; }    // applied in the next round (or on the way out)
+        else RR_UPDATE(skip);
         rs_barrier_lds();                       // fac / ca / cr / prow / rowbuf are rewritten by the next round
         RR_T(5);
     }
@@ -447,6 +497,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (t == 0) { atomicOr(&st->pad[1], 1); if (N.st_host) N.st_host->pad[1] = 1; }
         return;
     }
+    if (DEFER && pend_upd) RR_UPDATE(pend_skip);                                 // the last pivot's update, on the way out
     if (mine) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
@@ -521,11 +572,13 @@ int resident_regs_shape(int maxC, int min_ld, int mmax, int* rpw_max)
 
 hipError_t resident_regs_init()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2>),
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2, false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3>),
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
     return e;
 }
@@ -535,9 +588,13 @@ hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int 
     ResGroupParamsR p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk; p.rt = std::max(rt, rr_reg_rows(cfg));
     static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
     p.mute = mute;
-    if (cfg == 2) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);
-    else if (cfg == 3) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3>), dim3(grid, nodes), dim3(RR_NT_C), lds, s, p);
-    else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2>), dim3(grid, nodes), dim3(RR_NT_B), lds, s, p);
+    if (cfg == 2) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2, false>), dim3(grid, nodes), dim3(RR_NT_A), lds, s, p);
+    else if (cfg == 3) {
+        static const bool defer = [] { const char* e = std::getenv("LPX_RESIDENT_REGS_DEFER"); return !(e && e[0] == '0'); }();   // diagnostic: 0 = update at the end of its own round
+        if (defer) hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, true>), dim3(grid, nodes), dim3(RR_NT_C), lds, s, p);
+        else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, false>), dim3(grid, nodes), dim3(RR_NT_C), lds, s, p);
+    }
+    else hipLaunchKernelGGL((lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2, false>), dim3(grid, nodes), dim3(RR_NT_B), lds, s, p);
     return hipGetLastError();
 }
 
