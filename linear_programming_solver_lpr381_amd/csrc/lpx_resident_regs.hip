@@ -18,6 +18,8 @@
 //   the same with the 120 KB of LDS the row buffers leave free holding 11-12 MORE rows of the node (swept K0b-style after the register
 //     rows: +1.5 us per step): 26 + 11 rows -> 21 workgroups per node -> TWELVE nodes in flight: 1170-1180 nodes/s (24-26 register rows
 //     alike; 27: 1046, 28: 1024 -- the loop's own registers spill).
+//   and with the update of pivot k DEFERRED into round k+1's wait for the pivot row (template parameter DEFER, the round loop's
+//     comment): +8 % again.
 // Everything else -- the tagged-granule
 // exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
 // lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
