@@ -46,6 +46,7 @@ struct ResParams {
     double eps, tol;
     int max_iter, chunk;
     int mute;                                   // diagnostic (LPX_RESIDENT_TEST_MUTE=1|2): the last workgroup plays dead
+    int defer;                                  // the update of pivot k is applied in round k+1, in front of the pivot row's arrival
 };
 
 #ifdef LPX_STAMPS
@@ -116,6 +117,15 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     }
     __syncthreads();
 
+    // DEFERRED UPDATE (P.defer, r03): the rank-1 update of pivot k stays pending through the end of round k and the decision of round
+    // k+1 and is applied where a workgroup used to sleep and poll -- between the decision and the arrival of pivot k+1's row.  Its
+    // factors are the ones `facn` holds after the swap at the end of round k (the lookahead of round k+1 rewrites facn only later),
+    // its row is `prow` (rewritten by the gather only after the update), its owner's row `pend_skip` is already normalised in place.
+    // The owner of pivot k+1's row forms that row as the pending update would (mul, then sub: the bits the update stores), divides,
+    // publishes, leaves the result in the tile -- the pending update then skips that row as well -- and copies it to prow afterwards.
+    // Nothing else reads the tile in between: the lookahead runs behind the update as before.
+    const bool defer = P.defer != 0;
+    bool pend = false; int pend_skip = -1;
     RS_T0
     const int t_outer = t;
     for (int k = 0; k < P.chunk; ++k) {
@@ -171,21 +181,52 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         u64* xp = P.xp + 2 * (size_t)par * ld;
         if (w == owner) {
             double* prw = tile + (size_t)rl * ld;
-            const double piv = prw[q];
+            const bool fix = pend && rl != pend_skip;                           // row rl still lacks the pending update
+            const double fp = fix ? facn[rl] : 0.0;
+            double piv = prw[q];
+            if (fix) { const double prod = fp * prow[q]; piv = piv - prod; }
             __syncthreads();
             for (int j = t; j < C; j += RS_NT) {
-                const double p = prw[j] / piv;
+                double x = prw[j];
+                if (fix) { const double prod = fp * prow[j]; x = x - prod; }
+                const double p = x / piv;
                 rs_publish(xp + 2 * (size_t)j, p, gen);
                 prw[j] = p;
-                prow[j] = p;
+                if (!defer) prow[j] = p;                                        // defer: prow is still the pending update's row
             }
-        } else {
+            if (defer && fix)                                                   // the padding columns of the row get the pending update too
+                for (int j = C + t; j < ld; j += RS_NT) { const double prod = fp * prow[j]; prw[j] = prw[j] - prod; }
+        }
+        if (defer) {
+            const bool had = pend;
+            if (pend) {
+                const int skip2 = (w == owner) ? rl : -1;
+                for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+                    const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                    for (int i = 0; i < nloc; ++i) {
+                        if (i == pend_skip || i == skip2) continue;
+                        const double f = facn[i];
+                        double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                        double prod = f * p.x; v.x = v.x - prod;
+                        prod = f * p.y; v.y = v.y - prod;
+                        *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+                    }
+                }
+                pend = false;
+            }
+            rs_barrier_lds();                   // prow may be rewritten now
+            if (w == owner) { const double* prw = tile + (size_t)rl * ld; for (int j = t; j < C; j += RS_NT) prow[j] = prw[j]; }
+            else if (!had) { __builtin_amdgcn_s_sleep(RS_SLEEP_A); for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(RS_SLEEP_B); }
+        }
+        if (w != owner) {
             // Poll ONE granule (the last column, covered by the owner's last store instruction) until the row is
             // on its way: 255 workgroups re-reading 48 KB each per failed poll would saturate the fabric.
             // The owner needs 0.5-1 us to divide and store the row: sleep through that, then try the
             // whole gather ONCE -- when the row is already visible this saves the canary's round trip.
-            __builtin_amdgcn_s_sleep(RS_SLEEP_A);
-            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(RS_SLEEP_B);   // measured best: 20 (C = 769) ... 35 (C = 3073) x 64 cycles
+            if (!defer) {
+                __builtin_amdgcn_s_sleep(RS_SLEEP_A);
+                for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(RS_SLEEP_B);   // measured best: 20 (C = 769) ... 35 (C = 3073) x 64 cycles
+            }
             bool first = true;
             for (int base = t; base < C; base += RS_NT * RS_FETCH) {
                 int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
@@ -246,6 +287,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         __syncthreads();                        // the lookahead read columns qn and C-1 before anyone rewrites them
         RS_T(0);
         // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
+        if (defer) { pend = true; pend_skip = skip; }
+        else
         for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
             const double2 p = *reinterpret_cast<const double2*>(prow + j);
             for (int i = 0; i < nloc; ++i) {
@@ -266,6 +309,20 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
     if (hung) {
         if (t == 0) atomicOr(&st->pad[1], 1);
         return;
+    }
+    if (pend) {                                 // the last pivot's update, on the way out (its factors: facn, see the swap)
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + j);
+            for (int i = 0; i < nloc; ++i) {
+                if (i == pend_skip) continue;
+                const double f = facn[i];
+                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                double prod = f * p.x; v.x = v.x - prod;
+                prod = f * p.y; v.y = v.y - prod;
+                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+            }
+        }
+        __syncthreads();
     }
     for (int i = 0; i < nloc; ++i) {
         double* dst = P.T + (size_t)(row0 + i) * ld;
@@ -331,6 +388,8 @@ hipError_t launch_resident_primal(double* T, int ld, int R, int C, int grid, int
     p.xr = xr; p.xp = xp; p.xgen = xgen; p.eps = eps; p.tol = tol; p.max_iter = max_iter; p.chunk = chunk;
     static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
     p.mute = mute;
+    static const int defer = [] { const char* e = std::getenv("LPX_RESIDENT_DEFER"); return (e && e[0] == '0') ? 0 : 1; }();   // diagnostic: 0 = update at the end of its own round
+    p.defer = defer;
     hipLaunchKernelGGL(lpx_resident_primal, dim3(grid), dim3(RS_NT), lds, s, p);
     return hipGetLastError();
 }
