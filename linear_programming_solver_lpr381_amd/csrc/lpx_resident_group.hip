@@ -20,7 +20,7 @@
 
 namespace lpx {
 
-struct ResGroupParams { const ResNode* nodes; int chunk; int mute; };   // mute: diagnostic, LPX_RESIDENT_TEST_MUTE
+struct ResGroupParams { const ResNode* nodes; int chunk; int mute; int defer; };   // mute: diagnostic, LPX_RESIDENT_TEST_MUTE; defer: see the round loop
 
 #ifdef LPX_STAMPS
 #define RG_T0 unsigned long long rg_prev_ = __builtin_amdgcn_s_memtime();
@@ -94,6 +94,13 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     int qc = (phase != 1) ? first4_first_min_below(obj, rhsc, eps, s_v, s_i) : -1;
     bool publish_now = GP.chunk > 0;            // rows' (a, rhs) for the first round of this launch
 
+    // DEFERRED UPDATE (GP.defer, r03; as in lpx_resident_primal and lpx_resident_group_r): the rank-1 update of pivot k (factors `fac`,
+    // row `prow`, its owner's row `pend_skip` already normalised in place) is applied in round k+1 between the decision and the
+    // arrival of pivot k+1's row, where a workgroup used to sleep and poll.  Whoever reads the tile before that forms the value as the
+    // update would (mul, then sub): the republish path its two columns, the owner of pivot k+1's row that row -- in place, ahead of the
+    // rest, which then skips it.  The last pivot's update is applied behind the loop.
+    const bool defer = GP.defer != 0;
+    bool pend = false; int pend_skip = -1;
     RG_T0
     const int t_outer = t;
     for (int k = 0; k < GP.chunk; ++k) {
@@ -107,9 +114,15 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
             // to the dual loop is taken here already, so that the rows publish what that loop needs (their rhs).
             if (phase == 0 && (fdf_count >= N.fdf_guard || qc < 0)) { phase = 1; qc = -1; }
             if (t < nloc) {
-                const double rhs0 = tile[(size_t)t * ld + rhsc];
+                double rhs0 = tile[(size_t)t * ld + rhsc];
+                double a0 = (phase != 1 && qc >= 0) ? tile[(size_t)t * ld + qc] : 0.0;
+                if (pend && t != pend_skip) {                                   // the two columns as the pending update will leave them
+                    const double f = fac[t];
+                    double prod = f * prow[rhsc]; rhs0 = rhs0 - prod;
+                    if (phase != 1 && qc >= 0) { prod = f * prow[qc]; a0 = a0 - prod; }
+                }
                 double v = rhs0;
-                if (phase != 1) { const double a0 = qc >= 0 ? tile[(size_t)t * ld + qc] : 0.0; v = a0 > eps ? rhs0 / a0 : __builtin_inf(); }   // :229-233
+                if (phase != 1) v = a0 > eps ? rhs0 / a0 : __builtin_inf();     // :229-233
                 rs_publish(P.xr + 2 * ((size_t)((gen + 1u) & 1u) * P.mcap + row0 + t), v, gen + 1u);
             }
             publish_now = false;
@@ -165,6 +178,17 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         u64* xp = P.xp + 2 * (size_t)par * (gld + 8);
         if (w == owner) {
             double* prw = tile + (size_t)rl * ld;
+            if (pend && rl != pend_skip) {                                      // the pending update of THIS row first, in place
+                const double fp = fac[rl];
+                for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+                    const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                    double2 v = *reinterpret_cast<double2*>(prw + j);
+                    double prod = fp * p.x; v.x = v.x - prod;
+                    prod = fp * p.y; v.y = v.y - prod;
+                    *reinterpret_cast<double2*>(prw + j) = v;
+                }
+                __syncthreads();
+            }
             if (phase == 1) {                                                   // entering column of the dual loop, :79-91
                 if ((t >> 6) == 0) {
                     const int win = rs_exact_col_scan(rhsc, N.tol_dual, prw, obj, eps);
@@ -180,18 +204,42 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
                     const double p = prw[j] / piv;
                     rs_publish(xp + 2 * (size_t)j, p, gen);
                     prw[j] = p;
-                    prow[j] = p;
+                    if (!defer) prow[j] = p;                                    // defer: prow is still the pending update's row
                 }
             }
             if (phase == 1) {
                 __syncthreads();
                 if (t == 0) rs_publish(xp + 2 * (size_t)gld, (double)q, gen);   // header {q} behind the row
             }
+        }
+        const bool had_pending = pend;
+        if (defer) {
+            if (pend) {
+                const int skip2 = (w == owner) ? rl : -1;
+                for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+                    const double2 p = *reinterpret_cast<const double2*>(prow + j);
+                    for (int i = 0; i < nloc; ++i) {
+                        if (i == pend_skip || i == skip2) continue;
+                        const double f = fac[i];
+                        double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                        double prod = f * p.x; v.x = v.x - prod;
+                        prod = f * p.y; v.y = v.y - prod;
+                        *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+                    }
+                }
+                pend = false;
+            }
+            rs_barrier_lds();                   // prow may be rewritten now
+            if (w == owner && q >= 0) { const double* prw = tile + (size_t)rl * ld; for (int j = t; j < C; j += RS_NT) prow[j] = prw[j]; }
+        }
+        if (w == owner) {
         } else if (phase != 1) {
             // q is known (it came from the objective replica): exactly the consumer side of lpx_resident_primal --
             // sleep through the owner's divide + store, one look at the row, else poll one granule (the last column).
-            __builtin_amdgcn_s_sleep(15);
-            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
+            if (!had_pending) {
+                __builtin_amdgcn_s_sleep(15);
+                for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
+            }
             bool first = true;
             for (int base = t; base < C; base += RS_NT * RS_FETCH) {
                 int idx[RS_FETCH]; double val[RS_FETCH]; int cnt = 0;
@@ -209,9 +257,11 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         } else {
             // sleep through the owner's work, then ONE look at the header and the row together; if they are not all
             // there yet, wait for the header alone (one granule) and gather what is missing.
-            __builtin_amdgcn_s_sleep(15);
-            for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
-            if (phase == 1) __builtin_amdgcn_s_sleep(25);                       // the owner scans its row first
+            if (!had_pending) {
+                __builtin_amdgcn_s_sleep(15);
+                for (int z = 0; z < C; z += RS_NT) __builtin_amdgcn_s_sleep(5);
+                if (phase == 1) __builtin_amdgcn_s_sleep(25);                   // the owner scans its row first
+            }
             bool first = true;
             double hq = 0.0; unsigned hpend = 1u;
             for (int base = t; first || base < C; base += RS_NT * 3) {       // every lane fetches the header at least
@@ -290,6 +340,8 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
         __syncthreads();                        // the lookahead read columns qc and rhs before anyone rewrites them
         RG_T(0);
         // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
+        if (defer) { pend = true; pend_skip = skip; }
+        else
         for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
             const double2 p = *reinterpret_cast<const double2*>(prow + j);
             for (int i = 0; i < nloc; ++i) {
@@ -308,6 +360,20 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_group(ResGroupParams GP
     if (hung) {
         if (t == 0) { atomicOr(&st->pad[1], 1); if (N.st_host) N.st_host->pad[1] = 1; }
         return;
+    }
+    if (pend) {                                 // the last pivot's update, on the way out
+        for (int j = 2 * t; j < ld; j += 2 * RS_NT) {
+            const double2 p = *reinterpret_cast<const double2*>(prow + j);
+            for (int i = 0; i < nloc; ++i) {
+                if (i == pend_skip) continue;
+                const double f = fac[i];
+                double2 v = *reinterpret_cast<double2*>(tile + (size_t)i * ld + j);
+                double prod = f * p.x; v.x = v.x - prod;
+                prod = f * p.y; v.y = v.y - prod;
+                *reinterpret_cast<double2*>(tile + (size_t)i * ld + j) = v;
+            }
+        }
+        __syncthreads();
     }
     for (int i = 0; i < nloc; ++i) {
         double* dst = P.T + (size_t)(row0 + i) * gld;
@@ -352,6 +418,8 @@ hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, siz
     ResGroupParams p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;
     static const int mute = [] { const char* e = std::getenv("LPX_RESIDENT_TEST_MUTE"); return e ? std::atoi(e) : 0; }();
     p.mute = mute;
+    static const int defer = [] { const char* e = std::getenv("LPX_RESIDENT_DEFER"); return (e && e[0] == '0') ? 0 : 1; }();   // diagnostic: 0 = update at the end of its own round
+    p.defer = defer;
     hipLaunchKernelGGL(lpx_resident_group, dim3(grid, nodes), dim3(RS_NT), lds, s, p);
     return hipGetLastError();
 }
