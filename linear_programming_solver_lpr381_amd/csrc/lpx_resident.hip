@@ -284,7 +284,9 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
             }
             if (t == RS_NT - 1) facn[rpw] = obj[qn];
         }
-        __syncthreads();                        // the lookahead read columns qn and C-1 before anyone rewrites them
+        // the lookahead read columns qn and C-1 before anyone rewrites them.  LDS only: a full barrier would also wait for the
+        // acknowledgements of the lookahead's write-through stores, which nobody in this workgroup needs (lpx_resident.h)
+        rs_barrier_lds();
         RS_T(0);
         // ---- rank-1 update of the local rows, :250-256 -------------------------------------------------------
         if (defer) { pend = true; pend_skip = skip; }
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(RS_NT, 1) void lpx_resident_primal(ResParams P)
         }
         { double* sw = fac; fac = facn; facn = sw; }
         q = qn;
-        __syncthreads();
+        rs_barrier_lds();
         RS_T(5);
     }
 
