@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--bnb-nodes", type=int, default=3200, help="GLOBAL node budget of the config 4 leg (strong scaling)")
     ap.add_argument("--bnb-prune-n", type=int, default=60)
     ap.add_argument("--bnb-prune-m", type=int, default=12)
-    ap.add_argument("--bnb-concurrent", type=int, default=64)
+    ap.add_argument("--bnb-concurrent", type=int, default=256)
     ap.add_argument("--bnb-mid-n", type=int, default=128)
     ap.add_argument("--bnb-mid-m", type=int, default=32)
     ap.add_argument("--bnb-mid-seed", type=int, default=20251003)

@@ -599,7 +599,8 @@ int resident_group_plan(lpx_tableau** ts, int count, int* grid, int* slots, size
     // each in the LDS of one CU).  r01 / early r02 stopped at 8 nodes per launch; a 60-variable 0/1 program went from 7.2 k to
     // 21 k nodes/s when the limit fell (tools/probe_slots.py), node logs and pivot counts unchanged.  LPX_GROUP_SLOTS caps it.
     static const int max_slots = [] { const char* e = std::getenv("LPX_GROUP_SLOTS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 1 << 20; }();
-    for (int n = count < max_slots ? count : max_slots; n >= 1; --n) {
+    // (never more nodes than CUs: a node needs at least one workgroup -- a group of more than 256 nodes divided by zero here before r03)
+    for (int n = std::min(std::min(count, max_slots), cus); n >= 1; --n) {
         int g = cus / n;
         size_t need = 0;
         for (int i = 0; i < count; ++i) {

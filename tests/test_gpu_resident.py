@@ -430,3 +430,23 @@ def test_register_group_forms_agree_bit_for_bit(oracle):
         seen[name] = r.stdout.split("DIGEST", 1)[1].split()
     assert len({tuple(v) for v in seen.values()}) == 1, seen
     assert int(seen["default"][1]) > 1000, seen
+
+
+def test_group_of_more_nodes_than_compute_units(gpu, oracle):
+    """lpx_multi_run with 300 small LPs (more nodes than the chip has compute units: the planner divided by zero there before r03):
+    every one ends as the oracle says, bit for bit."""
+    hs, want = [], []
+    for k in range(300):
+        m, n = 3 + k % 5, 4 + k % 7
+        c, A, b = synth.dense_lp(m, n, seed=1000 + k)
+        T, basis = synth.primal_tableau_from(c, A, b)
+        Tr, br = T.copy(), basis.copy()
+        st, tr = oracle.primal_tableau(Tr, br)
+        want.append((st, len(tr), Tr, br))
+        hs.append(gpu.DeviceTableau.from_host(T, basis))
+    st, stats = gpu.multi_run(hs, [0] * len(hs))
+    for dt, s, k, (ws, wp, Tr, br) in zip(hs, st, stats, want):
+        Tg, bg = dt.download()
+        assert s == ws and k["pivots"] == wp
+        assert bg.tolist() == br.tolist() and np.array_equal(_bits(Tg), _bits(Tr))
+        dt.close()
