@@ -432,19 +432,26 @@ def test_register_group_forms_agree_bit_for_bit(oracle):
     assert int(seen["default"][1]) > 1000, seen
 
 
-def test_group_of_more_nodes_than_compute_units(gpu, oracle):
-    """lpx_multi_run with 300 small LPs (more nodes than the chip has compute units: the planner divided by zero there before r03):
-    every one ends as the oracle says, bit for bit."""
+@pytest.mark.parametrize("dual", [0, 1])
+def test_group_of_more_nodes_than_compute_units(gpu, oracle, dual):
+    """lpx_multi_run with 300 small LPs (more nodes than the chip has compute units: the planner divided by zero there before r03),
+    primal loop and dual loop: every one ends as the oracle says, bit for bit."""
     hs, want = [], []
     for k in range(300):
         m, n = 3 + k % 5, 4 + k % 7
         c, A, b = synth.dense_lp(m, n, seed=1000 + k)
         T, basis = synth.primal_tableau_from(c, A, b)
+        if dual:                                                       # one repaired >= row: -row <= -b'
+            T[k % m, :n] *= -1.0
+            T[k % m, -1] = -0.02 * T[k % m, -1]
         Tr, br = T.copy(), basis.copy()
-        st, tr = oracle.primal_tableau(Tr, br)
+        if dual:
+            st, tr, _ = oracle.dual_tableau(Tr, br, fdf_guard=10000, cleanup=1)
+        else:
+            st, tr = oracle.primal_tableau(Tr, br)
         want.append((st, len(tr), Tr, br))
         hs.append(gpu.DeviceTableau.from_host(T, basis))
-    st, stats = gpu.multi_run(hs, [0] * len(hs))
+    st, stats = gpu.multi_run(hs, [dual] * len(hs), None, gpu.default_opts(True, fdf_guard=10000, cleanup=1))
     for dt, s, k, (ws, wp, Tr, br) in zip(hs, st, stats, want):
         Tg, bg = dt.download()
         assert s == ws and k["pivots"] == wp
