@@ -16,3 +16,11 @@ def test_randomized_parity_sweep(gpu, oracle, seed):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_randomized_group_sweep(gpu, oracle):
+    """tests/fuzz_groups.py: lpx_multi_run on groups of up to 400 node LPs of mixed shapes and loops."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_groups.py"), "11", "10"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
