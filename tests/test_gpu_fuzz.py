@@ -24,3 +24,11 @@ def test_randomized_group_sweep(gpu, oracle):
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_randomized_revised_sweep(gpu, oracle):
+    """tests/fuzz_revised.py: the revised path on ragged shapes (one of them mid-size), pivot sequences equal to the oracle's."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_revised.py"), "5", "10"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
