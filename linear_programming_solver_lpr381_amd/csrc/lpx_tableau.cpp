@@ -678,7 +678,15 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     // launch does not leave its slice idle for long
     const lpx_run_opts* o0 = dual[0] ? dopts : popts;
     static const int chunk_env = [] { const char* e = std::getenv("LPX_GROUP_CHUNK"); return e ? std::atoi(e) : 0; }();   // diagnostic
-    const int chunk = cb ? (o0->batch > 0 ? o0->batch : 256) : (count > slots ? (chunk_env > 0 ? chunk_env : 96) : 1024);
+    // A group larger than the chip holds at a time goes out as ONE launch all the same (r03): the hardware hands workgroups to compute
+    // units in launch order, so the workgroups of node `slots` + k start as those of an earlier node leave -- a finished node's
+    // successor starts at once instead of at the next launch boundary, where the chip used to wait for the host (9 % of the cold
+    // config-4 search) and for the slowest node of the launch (6 %).  The earliest incomplete node is first in line for every unit
+    // that frees up, so it always completes its set; its early workgroups poll meanwhile (bounded waits of ~0.6 s against node
+    // run times of milliseconds).  LPX_GROUP_WALK=0: launches of `slots` nodes and 96 pivots, refilled by the host in between.
+    static const bool walk_env = [] { const char* e = std::getenv("LPX_GROUP_WALK"); return !(e && e[0] == '0'); }();
+    const bool walk = walk_env && cb == nullptr && count > slots;
+    const int chunk = cb ? (o0->batch > 0 ? o0->batch : 256) : (walk ? (1 << 20) : (count > slots ? (chunk_env > 0 ? chunk_env : 96) : 1024));
     std::vector<int> live(count);
     for (int i = 0; i < count; ++i) live[i] = i;
     std::vector<int> fired(count, 0);
@@ -691,7 +699,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     const bool snap_each_launch = cb != nullptr;
     long long launches = 0;
     while (!live.empty()) {
-        const int n = (int)live.size() < slots ? (int)live.size() : slots;
+        const int n = walk ? (int)live.size() : ((int)live.size() < slots ? (int)live.size() : slots);
         for (int k = 0; k < n; ++k) {
             g.h[k] = node[live[k]];
             lpx_tableau* t = ts[live[k]];
