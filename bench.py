@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--bnb-mid-concurrent", type=int, default=256)
     ap.add_argument("--bnb-mid-nodes", type=int, default=0, help="GLOBAL node budget of the mid-size leg (0 = to optimality)")
     ap.add_argument("--bnb-warm-nodes", type=int, default=8000, help="GLOBAL node budget of the warm-start leg")
-    ap.add_argument("--bnb-warm-concurrent", type=int, default=64)
+    ap.add_argument("--bnb-warm-concurrent", type=int, default=256)
     ap.add_argument("--knap-nodes", type=int, default=1000000, help="pop budget per rank (config 5 leg)")
     ap.add_argument("--revised-iters", type=int, default=300)
     args = ap.parse_args()
@@ -454,12 +454,26 @@ def main():
         if leg("bnb_warm"):
             res = bnb_leg(pb, "config 4, same sharded level search, children warm-started from the parent's final tableau (dual "
                               f"loop only) -- an engine mode, not the reference's algorithm; GLOBAL budget {args.bnb_warm_nodes} nodes, "
-                              f"{args.bnb_warm_concurrent} node LPs per batch",
+                              f"{args.bnb_warm_concurrent} node LPs per group call; node LPs on the register + LDS resident group kernel "
+                              "(twelve 7.9 MB nodes on chip, a group is one launch)",
                           warm_full=True, bnb_search=2, concurrent_nodes=args.bnb_warm_concurrent, max_nodes=args.bnb_warm_nodes)
-            rate = hbm_equivalent(res)
-            res["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": rate, "frac": rate / HBM_PEAK_GBS,
-                               "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
-                               "note": WARM_NOTE}
+            res["hbm_equivalent"] = {"unit": "GB/s", "rate": hbm_equivalent(res),
+                                     "note": "pivots x 16*R*C / wall: what a streaming engine would have to move -- the tableaux live in registers and LDS "
+                                             "here, HBM sees a node twice (load, store): a latency-bound kernel, not a roofline fraction"}
+            # the same search on the streaming form (LPX_WARM_RESIDENT=0, read per solve): 64 nodes per rolling batch through lpx_group_fused, HBM bound --
+            # the path of node LPs wider than the register kernel's 1536 columns, and the leg's `roofline` of rounds 2 and 3
+            os.environ["LPX_WARM_RESIDENT"] = "0"
+            try:
+                res_s = bnb_leg(pb, "the same search on the streaming kernels: two rolling batches of 64 node LPs through lpx_group_fused",
+                                warm_full=True, bnb_search=2, concurrent_nodes=64, max_nodes=args.bnb_warm_nodes)
+            finally:
+                del os.environ["LPX_WARM_RESIDENT"]
+            rate = hbm_equivalent(res_s)
+            res["streaming"] = {"workload": res_s["workload"], "nodes_per_s": res_s["nodes_per_s"], "lp_relaxations": res_s["lp_relaxations"],
+                                "pivots": res_s["pivots"], "wall_s": res_s["wall_s"],
+                                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": rate, "frac": rate / HBM_PEAK_GBS,
+                                             "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
+                                             "note": WARM_NOTE}}
             if rank == 0:
                 # the leg's kernel by itself: lpx_group_fused on 64 copies of the root tableau pivoting in lock step (every slot live), HIP
                 # events bound to each launch; traffic = the committed PMC passes of the same launch shape (tools/k4_headline.py)

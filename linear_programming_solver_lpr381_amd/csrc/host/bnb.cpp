@@ -406,11 +406,16 @@ void solve_group(Ctx& c, std::vector<NodeLP*>& group, int nvars)
     bool rolling = false;
     if (any_warm) {                                               // dual feasible start: only the dual loop (and its clean-up) runs
         dopt.fdf_guard = 0; dopt.cleanup = 1;
-        // a warm-started node needs a few dozen pivots: 64 of config 4's 8 MB nodes streaming together beat four resident at a
-        // time; small nodes (dozens to hundreds fit the chip's LDS side by side) stay on the resident kernel
-        size_t node_bytes = 0;
-        for (NodeLP* lp : group) node_bytes = std::max(node_bytes, sizeof(double) * (size_t)lp->R * (size_t)lp->C);
-        if (node_bytes > ((size_t)1 << 20)) {
+        // A warm-started node needs a few dozen pivots.  Until r03 the big ones (config 4: 8 MB) streamed 64 at a time through the
+        // one-launch-per-step kernel (15.8 MB of HBM traffic per node and pivot), because only four fitted the chip.  Twelve fit now
+        // (rows in registers + LDS), a whole group goes out as one launch and the hardware starts the next node as one leaves: the
+        // resident loop takes 0.45 ms per node whatever the HBM does -- 11.8 k against 8.2 k nodes/s on the same box, node logs
+        // and node objective values bitwise the same.  Streaming rolling batches remain for nodes wider than the register
+        // kernel's 1536 columns (and behind LPX_WARM_RESIDENT=0).
+        size_t node_bytes = 0; int node_cols = 0;
+        for (NodeLP* lp : group) { node_bytes = std::max(node_bytes, sizeof(double) * (size_t)lp->R * (size_t)lp->C); node_cols = std::max(node_cols, lp->C); }
+        const bool warm_stream = [] { const char* e = std::getenv("LPX_WARM_RESIDENT"); return e && e[0] == '0'; }();   // read per solve (bench.py times both forms in one process)
+        if ((warm_stream || node_cols > 1536) && node_bytes > ((size_t)1 << 20)) {
             dopt.resident = -1; po.resident = -1; rolling = group.size() > 1;
             static const int roll_batch = [] { const char* e = std::getenv("LPX_ROLL_BATCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 16; }();   // pivots between polls
             if (rolling && c.opt.batch <= 0) dopt.batch = po.batch = roll_batch;

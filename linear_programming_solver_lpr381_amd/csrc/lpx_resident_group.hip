@@ -413,6 +413,19 @@ hipError_t resident_group_init()
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 }
 
+// every node's initial state record in one launch: src is the host's pinned array, node i <-> src[i]
+__global__ __launch_bounds__(64) void lpx_resnode_states_scatter(const ResNode* __restrict__ nodes, const DevState* __restrict__ src)
+{
+    const int32_t* s = reinterpret_cast<const int32_t*>(src + blockIdx.x);
+    int32_t* d = reinterpret_cast<int32_t*>(nodes[blockIdx.x].st);
+    for (int k = threadIdx.x; k < (int)(sizeof(DevState) / sizeof(int32_t)); k += 64) d[k] = s[k];
+}
+hipError_t launch_resnode_states_scatter(const void* nodes_dev, const DevState* src_pinned, int count, hipStream_t s)
+{
+    hipLaunchKernelGGL(lpx_resnode_states_scatter, dim3(count), dim3(64), 0, s, static_cast<const ResNode*>(nodes_dev), src_pinned);
+    return hipGetLastError();
+}
+
 hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s)
 {
     ResGroupParams p; p.nodes = static_cast<const ResNode*>(nodes_dev); p.chunk = chunk;

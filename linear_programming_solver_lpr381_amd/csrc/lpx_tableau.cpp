@@ -560,7 +560,8 @@ int run_resident(lpx_tableau* t, const lpx_run_opts* o, lpx_pivot_cb cb, void* u
 // Resident group run: the nodes of a batch are solved a few at a time, each resident in the LDS of its own slice
 // of the chip (lpx_resident_group.hip).  Launches are `chunk` pivots long; after each one finished nodes leave and
 // waiting ones take their place, so the slices stay busy until the batch is done.
-struct ResGroupBuf { ResNode* d = nullptr; ResNode* h = nullptr; DevState* hs = nullptr; int cap = 0; hipStream_t stream = nullptr; };
+struct ResGroupBuf { ResNode* d = nullptr; ResNode* h = nullptr; DevState* hs = nullptr; int cap = 0; hipStream_t stream = nullptr;
+                     ParkDesc* pd_d = nullptr; ParkDesc* pd_h = nullptr; };   // pd: descriptors of the snapshot copies (one launch for a whole group)
 ResGroupBuf g_resgroup;
 
 // which kernel the last resident_group_plan chose: 0 = rows in LDS (lpx_resident_group), else the workgroup size of the
@@ -648,20 +649,35 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     if (!g.stream) LPX_HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (g.cap < count) {
         hipFree(g.d); if (g.h) hipHostFree(g.h); if (g.hs) hipHostFree(g.hs);
-        g.d = nullptr; g.h = nullptr; g.hs = nullptr; g.cap = 0;
+        hipFree(g.pd_d); if (g.pd_h) hipHostFree(g.pd_h);
+        g.d = nullptr; g.h = nullptr; g.hs = nullptr; g.pd_d = nullptr; g.pd_h = nullptr; g.cap = 0;
         const int c = count + 16;
         LPX_HIP_TRY(hipMalloc((void**)&g.d, sizeof(ResNode) * c));
         LPX_HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(ResNode) * c));
         LPX_HIP_TRY(hipHostMalloc((void**)&g.hs, sizeof(DevState) * c));
+        LPX_HIP_TRY(hipMalloc((void**)&g.pd_d, sizeof(ParkDesc) * c));
+        LPX_HIP_TRY(hipHostMalloc((void**)&g.pd_h, sizeof(ParkDesc) * c));
         g.cap = c;
     }
     const double t0 = now_ms();
     std::vector<ResNode> node(count);
+    // Per-node host work adds up when a group is a whole B&B level (8000 warm-started nodes: 0.24 s of stream waits, state uploads and
+    // snapshot copies in front of 0.3 s of kernel): every distinct stream is waited for once, the state records go up in one launch,
+    // the snapshots of a launch are one multi-copy launch.
+    std::vector<hipStream_t> waited;
+    auto wait_once = [&](hipStream_t st) -> int {
+        for (hipStream_t w : waited) if (w == st) return 0;
+        LPX_HIP_TRY(hipStreamSynchronize(st));
+        waited.push_back(st);
+        return 0;
+    };
     for (int i = 0; i < count; ++i) {
         lpx_tableau* t = ts[i];
-        LPX_HIP_TRY(hipStreamSynchronize(t->stream));                   // node assembly ran on the node's own stream
-        { int rc = resident_buffers(t); if (rc) return rc; }
-        LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        { int rc = wait_once(t->stream); if (rc) return rc; }          // node assembly ran on the node's own stream
+        if (!t->xr) {
+            { int rc = resident_buffers(t); if (rc) return rc; }
+            LPX_HIP_TRY(hipStreamSynchronize(t->stream));
+        }
         const lpx_run_opts* o = dual[i] ? dopts : popts;
         ResNode& n = node[i];
         n.T = t->T; n.ld = t->ld; n.R = t->R; n.C = t->C; n.basis = t->basis; n.trace = t->trace; n.trace_cap = t->trace_cap;
@@ -672,8 +688,12 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
         init.status = LPX_RUNNING; init.r = -1; init.q = -1; init.qn = -1; init.phase = dual[i] ? 0 : 2;
         g.hs[i] = init;
         n.st_host = &g.hs[i];
-        LPX_HIP_TRY(hipMemcpyAsync(t->st, &g.hs[i], sizeof(DevState), hipMemcpyHostToDevice, g.stream));
     }
+    // every node's initial state record: one launch reading the pinned array (node i <-> g.hs[i])
+    std::memcpy(g.h, node.data(), sizeof(ResNode) * (size_t)count);
+    LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * (size_t)count, hipMemcpyHostToDevice, g.stream));
+    LPX_HIP_TRY(launch_resnode_states_scatter(g.d, g.hs, count, g.stream));
+    LPX_HIP_TRY(hipStreamSynchronize(g.stream));                        // g.h / g.d are rewritten per launch below
     // launch length: long enough to hide the launch + reload (~30 us), short enough that a node finishing inside a
     // launch does not leave its slice idle for long
     const lpx_run_opts* o0 = dual[0] ? dopts : popts;
@@ -700,15 +720,23 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     long long launches = 0;
     while (!live.empty()) {
         const int n = walk ? (int)live.size() : ((int)live.size() < slots ? (int)live.size() : slots);
+        int nsnap = 0; size_t maxd = 2;
         for (int k = 0; k < n; ++k) {
             g.h[k] = node[live[k]];
             lpx_tableau* t = ts[live[k]];
             if (snap_each_launch || !snapped[live[k]]) {
                 before[live[k]] = g.hs[live[k]];
-                LPX_HIP_TRY(hipMemcpyAsync(t->xbasis, t->basis, sizeof(int32_t) * (size_t)(t->R - 1), hipMemcpyDeviceToDevice, g.stream));
-                LPX_HIP_TRY(hipMemcpyAsync(t->xT, t->T, sizeof(double) * (size_t)t->R * t->ld, hipMemcpyDeviceToDevice, g.stream));
+                ParkDesc& d = g.pd_h[nsnap++];
+                d.srcT = t->T; d.dstT = t->xT; d.srcB = t->basis; d.dstB = t->xbasis;
+                d.doubles = (size_t)t->R * t->ld; d.m = t->R - 1; d.pad = 0;
+                maxd = std::max(maxd, d.doubles);
                 snapped[live[k]] = 1;
             }
+        }
+        if (nsnap > 0) {                        // the snapshots of this launch: one multi-copy launch (lpx_park_many)
+            LPX_HIP_TRY(hipMemcpyAsync(g.pd_d, g.pd_h, sizeof(ParkDesc) * (size_t)nsnap, hipMemcpyHostToDevice, g.stream));
+            const int bpn = (int)std::min<size_t>(256, std::max<size_t>(1, maxd / 2 / 256 / 4));
+            LPX_HIP_TRY(launch_park_many(g.pd_d, nsnap, bpn, g.stream));
         }
         // the kernel writes each node's new state into the pinned mirror (ResNode::st_host): nothing is copied back
         LPX_HIP_TRY(hipMemcpyAsync(g.d, g.h, sizeof(ResNode) * n, hipMemcpyHostToDevice, g.stream));

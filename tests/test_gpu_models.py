@@ -680,8 +680,9 @@ def test_rolling_batches_dual_phase_machine_survives_suspension(gpu, oracle):
 
 def test_warm_search_is_the_same_search_however_the_batches_roll(gpu):
     """The rolling batches only decide WHEN a warm-started child's run continues: node log, node objective values (bitwise),
-    LP count and pivot total of the warm search on a 0/1 program whose node tableaux (1.2 MB) take the streaming kernels are the
-    same whether a run is suspended as soon as half of the batch is left, only when one node is left, or polled every 4 pivots."""
+    LP count and pivot total of the warm search on a 0/1 program whose node tableaux are 1.2 MB are the same whether, on the
+    streaming kernels, a run is suspended as soon as half of the batch is left, only when one node is left, or polled every 4
+    pivots -- and the same again on the resident group kernel, which is where such nodes run by default since r03."""
     import subprocess, sys, os, textwrap, json
     code = textwrap.dedent('''
         import json, numpy as np
@@ -694,9 +695,11 @@ def test_warm_search_is_the_same_search_however_the_batches_roll(gpu):
     ''')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"LPX_ROLL_DIV": "1000000"}, {"LPX_ROLL_BATCH": "4", "LPX_ROLL_DIV": "3"}):
+    # the streaming rolling batches three ways (LPX_WARM_RESIDENT=0) and the default: the same nodes on the resident group kernel
+    for env in ({"LPX_WARM_RESIDENT": "0"}, {"LPX_WARM_RESIDENT": "0", "LPX_ROLL_DIV": "1000000"},
+                {"LPX_WARM_RESIDENT": "0", "LPX_ROLL_BATCH": "4", "LPX_ROLL_DIV": "3"}, {}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0][0] > 300 and outs[0][1] > 1000
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]

@@ -98,6 +98,10 @@ for key in ("bnb", "bnb_warm", "bnb_prune", "bnb_prune_mid"):
         extra += f", incumbent {b['incumbent']}" if b.get("incumbent") is not None else ""
         extra += f", pruned by bound {b['pruned_by_bound']:.0f}, incumbent updates {b['incumbent_updates']:.0f}" if "pruned_by_bound" in b else ""
         print(f"* {key}: **{b['nodes_per_s']:.0f} nodes/s** ({b['lp_relaxations']:.0f} LPs, {b['pivots']:.0f} pivots, {b['wall_s']:.3f} s{extra})")
+        st = b.get("streaming")
+        if st:
+            print(f"  * the same search on the streaming kernels (two rolling batches of 64 through lpx_group_fused): {st['nodes_per_s']:.0f} nodes/s "
+                  f"({st['wall_s']:.3f} s), whole-leg fraction **{st['roofline']['frac']:.3f}** of 8 TB/s")
 kn = bench["knapsack"]
 print(f"* knapsack: {kn['nodes_per_s'] / 1e6:.2f} M nodes/s ({kn['popped']:.0f} pops, {kn['launches']} launches, device calls {100 * kn['device_call_fraction_of_wall']:.0f} % of the wall time)")
 cb = bench["cpu_baseline"]
