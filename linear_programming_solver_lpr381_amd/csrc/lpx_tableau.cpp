@@ -719,7 +719,7 @@ int run_resident_group(lpx_tableau** ts, const int* dual, int count, const lpx_r
     const bool snap_each_launch = cb != nullptr;
     long long launches = 0;
     while (!live.empty()) {
-        const int n = walk ? (int)live.size() : ((int)live.size() < slots ? (int)live.size() : slots);
+        const int n = walk ? (int)std::min<size_t>(live.size(), 65535) : ((int)live.size() < slots ? (int)live.size() : slots);   // gridDim.y <= 65535
         int nsnap = 0; size_t maxd = 2;
         for (int k = 0; k < n; ++k) {
             g.h[k] = node[live[k]];
