@@ -3,8 +3,8 @@
 // Cold branch-and-bound nodes (every node re-solved from the slack basis as the reference does, Models/Branch&Bound.cs:148) are
 // bound by what fits on chip: four 7.9 MB tableaux fill the 40 MB of LDS, and the loop is latency bound (two cross-CU exchanges per
 // pivot), so the chip idles through most of a step.  The register files hold three times as much as the LDS (512 KB per CU,
-// 128 MB in all).  Here workgroup w of a node keeps RPW consecutive rows in VGPRs: lane t owns the column pair (2t, 2t+1) of every
-// one of them (a workgroup is as wide as the tableau: NT >= ld / 2 lanes), so
+// 128 MB in all).  Here workgroup w of a node keeps RPW consecutive rows in VGPRs: lane t owns KC adjacent columns (KC t .. KC t + KC - 1)
+// of every one of them (a workgroup is as wide as the tableau: NT >= ld / KC lanes), so
 //   * the rank-1 update is register arithmetic (row factor broadcast from LDS, the lane's pivot-row pair read once per pivot);
 //   * a COLUMN of the local rows (entering column -> factors; RHS and next entering column -> the ratios the rows publish) is
 //     the RPW registers of ONE lane, which drops them into LDS;
@@ -19,11 +19,12 @@
 //     rows: +1.5 us per step): 26 + 11 rows -> 21 workgroups per node -> TWELVE nodes in flight: 1170-1180 nodes/s (24-26 register rows
 //     alike; 27: 1046, 28: 1024 -- the loop's own registers spill).
 //   and with the update of pivot k DEFERRED into round k+1's wait for the pivot row (template parameter DEFER, the round loop's
-//     comment): +8 % again.
+//     comment): +8 % again.  A group of more nodes than the chip holds is ONE launch (lpx_tableau.cpp, run_resident_group): the hardware
+//     starts the next node's workgroups as an earlier node's leave (+11 %: 1.31 k nodes/s on the cold config-4 search).
 // Everything else -- the tagged-granule
 // exchanges, the replicated state machine of the dual path, the lookahead, the bounded waits, the arithmetic per element -- is that of
 // lpx_resident_group (bit-identical results; the same tests).  LDS holds the objective replica, the pivot row, the gathered column,
-// the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB.
+// the owner's row (for the dual loop's column scan) and the small column buffers: ~40 KB; the rest the node's LDS rows.
 #include "lpx_resident.h"
 #include <algorithm>
 #include <cstdlib>
