@@ -474,6 +474,10 @@ def main():
                                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": rate, "frac": rate / HBM_PEAK_GBS,
                                              "basis": f"pivots x 16*{R0}*{C0} B (root shape: a lower bound) / whole-leg wall time, host work included",
                                              "note": WARM_NOTE}}
+            # rounds 2 and 3 quoted this leg's whole-leg HBM fraction as `bnb_warm.roofline`: it is the STREAMING form's figure (the default
+            # form above moves no tableau through HBM per pivot, so it has no HBM roofline)
+            res["roofline"] = dict(res["streaming"]["roofline"], form="streaming kernels (bnb_warm.streaming), not the default resident form",
+                                   nodes_per_s=res_s["nodes_per_s"])
             if rank == 0:
                 # the leg's kernel by itself: lpx_group_fused on 64 copies of the root tableau pivoting in lock step (every slot live), HIP
                 # events bound to each launch; traffic = the committed PMC passes of the same launch shape (tools/k4_headline.py)

@@ -94,7 +94,7 @@ print(f"* config 3: {rv['us_per_iteration']:.1f} us per iteration ({rv['iteratio
 for key in ("bnb", "bnb_warm", "bnb_prune", "bnb_prune_mid"):
     b = bench.get(key)
     if b:
-        extra = f", whole-leg fraction **{b['roofline']['frac']:.3f}**" if "roofline" in b else ""
+        extra = f", whole-leg fraction **{b['roofline']['frac']:.3f}**" if "roofline" in b and "streaming" not in b else ""
         extra += f", incumbent {b['incumbent']}" if b.get("incumbent") is not None else ""
         extra += f", pruned by bound {b['pruned_by_bound']:.0f}, incumbent updates {b['incumbent_updates']:.0f}" if "pruned_by_bound" in b else ""
         print(f"* {key}: **{b['nodes_per_s']:.0f} nodes/s** ({b['lp_relaxations']:.0f} LPs, {b['pivots']:.0f} pivots, {b['wall_s']:.3f} s{extra})")
