@@ -56,7 +56,8 @@ row("K4f primal step, headline LP 4097x12289", "lpx_pivot_fused", 16.0 * R * C, 
 row("K4 in-place update, north-star 4096x8192", "lpx_update_mb", 16.0 * 4096 * 8192, grid=2097152)
 row("K4f primal step, config 2 (25 MB, cache resident)", "lpx_pivot_fused_c", 16.0 * 1025 * 3073)
 row("K0 resident primal loop, config 2 (one launch per solve)", "lpx_resident_primal", note="latency bound: two cross-CU exchanges per pivot, tableau in LDS")
-row("K0r register + LDS resident group, config 4 cold (grid = lanes x workgroups per node, nodes; 96-pivot launches)", "lpx_resident_group_r", note="latency bound (mean / 96 = us per pivot step of the nodes in flight)")
+row("K0r register + LDS resident group, config 4 (twelve nodes on chip; a launch is a whole group: grid = lanes x workgroups per node, nodes of the group)", "lpx_resident_group_r<512, 26", note="latency bound: a launch lasts (nodes of the group / 12 slots) x pivots per node x ~11.2 us")
+row("K0r narrow form, mid-size IP nodes (3 workgroups per node, 85 on chip; a launch is a whole group)", "lpx_resident_group_r<512, 40", note="latency bound")
 row("K0b LDS-resident group (root LPs, small nodes)", "lpx_resident_group<", note="latency bound")
 row("K4g group step, warm config 4 (64-slot grid; live slots vary)", "lpx_group_fused", grid="12058624x1", note="two batches' windows overlap on the device here: durations are not additive -- the kernel by itself is the line under the table")
 row("K5 rv_price, config 3", "rv_price", 8.0 * 4096 * 8192)
