@@ -134,6 +134,7 @@ hipError_t resident_group_init();
 hipError_t resident_regs_init();
 int resident_regs_shape(int maxC, int min_ld, int mmax, int* rpw_max);   // 0 = does not fit; else the kernel configuration (1, 2, 3)
 size_t resident_regs_lds(int R, int C, int rt, int cfg);
+size_t resident_regs_lds_budget();                  // dynamic LDS a workgroup of the register-resident kernel may ask for
 hipError_t launch_resnode_states_scatter(const void* nodes_dev, const DevState* src_pinned, int count, hipStream_t s);
 hipError_t launch_resident_regs(const void* nodes_dev, int nodes, int grid, int cfg, int rt, size_t lds, int chunk, hipStream_t s);
 hipError_t launch_resident_group(const void* nodes_dev, int nodes, int grid, size_t lds, int chunk, hipStream_t s);

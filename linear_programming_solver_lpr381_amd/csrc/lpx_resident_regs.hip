@@ -544,7 +544,10 @@ static constexpr int RR_NT_C = 512, RR_RPW_C = 26;     // up to 1536 columns, TH
 
 static int rr_kc(int cfg) { return cfg == 3 ? 3 : 2; }
 static int rr_reg_rows(int cfg) { return cfg == 1 ? RR_RPW_B : (cfg == 2 ? RR_RPW_A : RR_RPW_C); }
-static constexpr size_t RR_LDS_BUDGET = (size_t)158 * 1024;   // dynamic LDS of a workgroup (160 KB per CU, the static scan records beside it)
+// Dynamic LDS a workgroup may ask for: the CU's 160 KB less the kernels' static records (measured by resident_regs_init; 464 B today).
+// 158 KB held one LDS row less for nodes of 1285+ columns (levels 3+ of config 4): 11 nodes on chip instead of 12.
+static size_t g_rr_lds_budget = (size_t)158 * 1024;
+size_t resident_regs_lds_budget() { return g_rr_lds_budget; }
 
 // rt = rows a workgroup may hold (the per-row arrays are sized for it); the rows beyond the configuration's register rows live in LDS
 size_t resident_regs_lds(int R, int C, int rt, int cfg)
@@ -568,21 +571,27 @@ int resident_regs_shape(int maxC, int min_ld, int mmax, int* rpw_max)
     if (!cfg) return 0;
     const int regs = rr_reg_rows(cfg), ld = rr_tile_width(maxC, rr_kc(cfg));
     const long long fixed = 3LL * ld + ((mmax + 1) & ~1) + 4LL * regs + 2;
-    const long long left = (long long)(RR_LDS_BUDGET / sizeof(double)) - fixed;
+    const long long left = (long long)(g_rr_lds_budget / sizeof(double)) - fixed;
     *rpw_max = regs + (lds_rows && left > 0 ? (int)(left / (ld + 4)) : 0);
     return cfg;
 }
 
 hipError_t resident_regs_init()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2, false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RR_LDS_BUDGET);
+    const void* ks[4] = {reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_A, RR_RPW_A, 3, 2, false>),
+                         reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_B, RR_RPW_B, 2, 2, false>),
+                         reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, true>),
+                         reinterpret_cast<const void*>(lpx_resident_group_r<RR_NT_C, RR_RPW_C, 2, 3, false>)};
+    size_t stat = 512;
+    for (const void* k : ks) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, k) == hipSuccess) stat = std::max(stat, (size_t)a.sharedSizeBytes);
+        else (void)hipGetLastError();
+    }
+    g_rr_lds_budget = ((size_t)160 * 1024 - stat) & ~(size_t)15;
+    hipError_t e = hipSuccess;
+    for (const void* k : ks)
+        if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_rr_lds_budget);
     return e;
 }
 

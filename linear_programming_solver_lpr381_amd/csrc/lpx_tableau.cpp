@@ -584,7 +584,7 @@ static int resident_regs_plan(lpx_tableau** ts, int count, int cus, int* grid, s
     { const int rpw = (mmax + g - 1) / g; g = (mmax + rpw - 1) / rpw; }          // no idle workgroups for the tallest node
     size_t need = 0;
     for (int i = 0; i < count; ++i) need = std::max(need, resident_regs_lds(ts[i]->R, ts[i]->C, rpw_max, n));
-    if (need > (size_t)158 * 1024) return 0;
+    if (need > resident_regs_lds_budget()) return 0;
     *grid = g; *lds = need; *nt = n; *rt = rpw_max;
     return cus / g;
 }
